@@ -1,0 +1,583 @@
+// 4x4 / stride 2 / pad 1 convolution family as implicit GEMMs on the shared f32-MFMA core.
+//
+//   conv forward         y[m=(n,ho,wo)][co] = sum_{kh,kw,ci} act(x)[n,2ho-1+kh,2wo-1+kw,ci] * wp[co][kh][kw][ci]
+//   transposed forward   four sub-pixel phases (ph,pw); for each, a 2x2-tap conv at input resolution:
+//                        y[n,2a+ph,2b+pw][co] = sum_{th,tw,ci} act(x)[n,a+ph-th,b+pw-tw,ci] * wp[ph,pw][co][th][tw][ci]
+//   weight gradient      dw[c1][c2][kh][kw] = sum_{m=(n,a,b)} P[m][c1] * Q[n,2a-1+kh,2b-1+kw][c2]
+//
+// Activations are NHWC, so a K slice (fixed tap, run of input channels) is contiguous in memory.
+// The previous layer's BatchNorm + LeakyReLU is applied while the operand is loaded; zero padding
+// is applied after that transform.  The forward kernels also emit per-workgroup partial sums of the
+// raw output and of its square per output channel (BatchNorm statistics), each workgroup walking
+// several M tiles so the number of partial rows stays bounded.
+//
+// Spatial sizes must be powers of two (64x64 and 128x128 frames and their halvings).
+#include "gemm_core.h"
+#include "../../include/dvae_hip.h"
+
+#define ST(s) ((hipStream_t)(s))
+#define CONV_MAX_PARTS 1024
+
+static inline int ilog2(int64_t v) {
+  int l = 0;
+  while ((1LL << l) < v) ++l;
+  return l;
+}
+static inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_conv_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int64_t A, int64_t Bc) {
+  const int64_t total = A * Bc * 16;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // destination index i = (a*16 + tap)*Bc + b
+    const int64_t b = i % Bc, t = (i / Bc) % 16, a = i / (Bc * 16);
+    wp[i] = w[(a * Bc + b) * 16 + t];
+  }
+}
+
+__global__ void pack_deconv_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int64_t Kc, int64_t Nc) {
+  const int64_t per_phase = Nc * 4 * Kc;
+  const int64_t total = 4 * per_phase;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // destination index i = ((phase*Nc + n)*4 + tap)*Kc + k
+    const int64_t k = i % Kc, tap = (i / Kc) % 4, n = (i / (Kc * 4)) % Nc, phase = i / per_phase;
+    const int ph = (int)(phase >> 1), pw = (int)(phase & 1), th = (int)(tap >> 1), tw = (int)(tap & 1);
+    const int kh = ph == 0 ? (th == 0 ? 1 : 3) : (th == 0 ? 0 : 2);
+    const int kw = pw == 0 ? (tw == 0 ? 1 : 3) : (tw == 0 ? 0 : 2);
+    wp[i] = w[((k * Nc + n) * 4 + kh) * 4 + kw];
+  }
+}
+
+extern "C" int dvae_pack_conv_w_f32(const float* w, float* wp, int64_t A, int64_t Bc, dvae_stream_t stream) {
+  DVAE_REQUIRE(A > 0 && Bc > 0, "pack_conv_w: empty");
+  int64_t nb = ceil_div64(A * Bc * 16, 256);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(pack_conv_w_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), w, wp, A, Bc);
+  DVAE_LAUNCH_CHECK("pack_conv_w");
+  return 0;
+}
+
+extern "C" int dvae_pack_deconv_w_f32(const float* w, float* wp, int64_t Kc, int64_t Nc, dvae_stream_t stream) {
+  DVAE_REQUIRE(Kc > 0 && Nc > 0, "pack_deconv_w: empty");
+  int64_t nb = ceil_div64(Kc * Nc * 16, 256);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(pack_deconv_w_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), w, wp, Kc, Nc);
+  DVAE_LAUNCH_CHECK("pack_deconv_w");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward kernels
+// ------------------------------------------------------------------------------------------------
+struct ConvArgs {
+  const float* x;
+  const float* in_scale;
+  const float* in_shift;
+  const float* wp;
+  float* y;
+  float* stats;  // [parts][2][Cout] or nullptr
+  int64_t M;     // GEMM rows per phase
+  int in_act;
+  int H, W;      // input spatial size
+  int lh, lw;    // log2 of the row-index grid (conv: Ho,Wo ; deconv: H,W)
+  int Cin, Cout, K;
+  int mtiles;
+};
+
+// A operand of the forward implicit GEMMs.  MODE 0: conv (16 taps, input pixel 2*o-1+k);
+// MODE 1: transposed conv phase (4 taps, input pixel a+ph-th).  C1: single input channel.
+template <int V4, int MODE, bool C1>
+struct ConvALoader {
+  const ConvArgs& g;
+  int ph, pw;
+  int64_t base[V4];
+  int h0[V4], w0[V4];
+  bool ok[V4];
+  __device__ __forceinline__ ConvALoader(const ConvArgs& g_, int ph_, int pw_) : g(g_), ph(ph_), pw(pw_) {}
+  __device__ __forceinline__ void set_tile(int64_t m0) {
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      int row, ch;
+      kc_pos(v, row, ch);
+      const int64_t m = m0 + row;
+      ok[v] = m < g.M;
+      const int b = (int)(m & ((1 << g.lw) - 1));
+      const int a = (int)((m >> g.lw) & ((1 << g.lh) - 1));
+      const int64_t n = m >> (g.lw + g.lh);
+      base[v] = n * g.H * g.W * g.Cin;
+      if (MODE == 0) {
+        h0[v] = 2 * a - 1;
+        w0[v] = 2 * b - 1;
+      } else {
+        h0[v] = a + ph;
+        w0[v] = b + pw;
+      }
+    }
+  }
+  __device__ __forceinline__ void fetch(int kt, float4 (&r)[V4]) const {
+    const int ch = threadIdx.x & 7;
+    const int k = kt * 32 + 4 * ch;
+    if (C1) {
+      // K = 16 (conv only): k = kh*4 + kw, the chunk is one filter row
+      const int kh = ch;
+#pragma unroll
+      for (int v = 0; v < V4; ++v) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        const int hi = h0[v] + kh;
+        if (ok[v] && k < g.K && hi >= 0 && hi < g.H) {
+          const float* p = g.x + base[v] + (int64_t)hi * g.W;
+#pragma unroll
+          for (int kw = 0; kw < 4; ++kw) {
+            const int wi = w0[v] + kw;
+            if (wi >= 0 && wi < g.W) t[kw] = p[wi];
+          }
+        }
+        r[v] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+      return;
+    }
+    const int tap = k / g.Cin;
+    const int ci = k - tap * g.Cin;
+    int dh, dw;
+    if (MODE == 0) {
+      dh = tap >> 2;
+      dw = tap & 3;
+    } else {
+      dh = -(tap >> 1);
+      dw = -(tap & 1);
+    }
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      const int hi = h0[v] + dh, wi = w0[v] + dw;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok[v] && k < g.K && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) {
+        val = *reinterpret_cast<const float4*>(g.x + base[v] + ((int64_t)hi * g.W + wi) * g.Cin + ci);
+        val = affine_act4(val, g.in_scale, g.in_shift, ci, g.in_act);
+      }
+      r[v] = val;
+    }
+  }
+};
+
+template <class T, int MODE, bool C1>
+__global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * T::STAGE_FLOATS];
+  const int phase = blockIdx.z, ph = phase >> 1, pw = phase & 1;
+  const int64_t n0 = (int64_t)blockIdx.y * T::BN;
+  const int ktiles = (g.K + 31) / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wn = wave % T::WGN, wm = wave / T::WGN;
+  const int l31 = lane & 31;
+
+  ConvALoader<T::A_V4, MODE, C1> la(g, ph, pw);
+  KCLoader<T::B_V4> lb{g.wp + (int64_t)phase * g.Cout * g.K, (int64_t)g.K, (int64_t)g.Cout, (int64_t)g.K, n0};
+
+  float s1[T::TN], s2[T::TN];
+#pragma unroll
+  for (int j = 0; j < T::TN; ++j) s1[j] = s2[j] = 0.f;
+
+  for (int mt = blockIdx.x; mt < g.mtiles; mt += gridDim.x) {
+    const int64_t m0 = (int64_t)mt * T::BM;
+    la.set_tile(m0);
+    f32x16 acc[T::TM][T::TN];
+    zero_acc<T>(acc);
+    gemm_mainloop<T>(la, lb, 0, ktiles, smem, acc);
+
+    // store raw output
+    for_each_acc<T>(acc, [&](int r, int c, float v) {
+      const int64_t m = m0 + r, n = n0 + c;
+      if (m < g.M && n < g.Cout) {
+        int64_t orow;
+        if (MODE == 0) {
+          orow = m;
+        } else {
+          const int b = (int)(m & ((1 << g.lw) - 1));
+          const int a = (int)((m >> g.lw) & ((1 << g.lh) - 1));
+          const int64_t img = m >> (g.lw + g.lh);
+          orow = (img * (2 * g.H) + (2 * a + ph)) * (2 * g.W) + (2 * b + pw);
+        }
+        g.y[orow * g.Cout + n] = v;
+      }
+    });
+    if (g.stats) {
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r];
+            s1[j] += v;
+            s2[j] += v * v;
+          }
+    }
+  }
+
+  if (g.stats) {
+    // lanes l and l+32 hold the same column; waves with equal wn hold the same columns
+    float* red = smem;  // [4 waves][TN*32][2]
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+      const float a = s1[j] + __shfl_xor(s1[j], 32);
+      const float b = s2[j] + __shfl_xor(s2[j], 32);
+      if (lane < 32) {
+        red[((wave * T::TN + j) * 32 + l31) * 2 + 0] = a;
+        red[((wave * T::TN + j) * 32 + l31) * 2 + 1] = b;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < T::BN) {
+      const int col = threadIdx.x;
+      const int cwn = col / (T::TN * 32), j = (col / 32) % T::TN, l = col & 31;
+      float a = 0.f, b = 0.f;
+      for (int m = 0; m < T::WGM; ++m) {
+        const int w = m * T::WGN + cwn;
+        a += red[((w * T::TN + j) * 32 + l) * 2 + 0];
+        b += red[((w * T::TN + j) * 32 + l) * 2 + 1];
+      }
+      const int64_t n = n0 + col;
+      if (n < g.Cout) {
+        const int64_t part = (int64_t)phase * gridDim.x + blockIdx.x;
+        g.stats[(part * 2 + 0) * g.Cout + n] = a;
+        g.stats[(part * 2 + 1) * g.Cout + n] = b;
+      }
+    }
+    (void)wm;
+  }
+}
+
+extern "C" int64_t dvae_conv_stat_parts(int64_t M_rows) {
+  (void)M_rows;
+  return 4 * CONV_MAX_PARTS;
+}
+
+template <int MODE>
+static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t stream) {
+  const bool c1 = g.Cin == 1;
+#define LAUNCH(TILE, C1FLAG)                                                                         \
+  {                                                                                                  \
+    g.mtiles = (int)ceil_div64(g.M, TILE::BM);                                                       \
+    int gx = g.mtiles < CONV_MAX_PARTS ? g.mtiles : CONV_MAX_PARTS;                                  \
+    dim3 grid(gx, (unsigned)ceil_div64(g.Cout, TILE::BN), phases);                                   \
+    hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG>), grid, dim3(256), 0, stream, g);        \
+  }
+  typedef Tile<128, 128, 2, 2, true, true> T128;
+  typedef Tile<128, 64, 4, 1, true, true> T64;
+  typedef Tile<128, 32, 4, 1, true, true> T32;
+  if (c1) {
+    if (g.Cout > 32) LAUNCH(T64, true) else LAUNCH(T32, true)
+  } else if (g.Cout > 64) {
+    LAUNCH(T128, false)
+  } else if (g.Cout > 32) {
+    LAUNCH(T64, false)
+  } else {
+    LAUNCH(T32, false)
+  }
+#undef LAUNCH
+  DVAE_LAUNCH_CHECK(name);
+  return 0;
+}
+
+// number of stat partial rows a forward launch writes
+static int64_t conv_parts_written(int64_t M, int phases) {
+  // all tile shapes use BM = 128
+  int64_t mt = ceil_div64(M, 128);
+  if (mt > CONV_MAX_PARTS) mt = CONV_MAX_PARTS;
+  return mt * phases;
+}
+
+extern "C" int dvae_conv4s2_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
+                                    const float* wp, float* y, float* stat_partials, int64_t N, int64_t H, int64_t W,
+                                    int64_t Cin, int64_t Cout, dvae_stream_t stream) {
+  DVAE_REQUIRE(N > 0 && Cout > 0, "conv4s2_fwd: empty");
+  DVAE_REQUIRE(is_pow2(H) && is_pow2(W) && H >= 2 && W >= 2, "conv4s2_fwd: H and W must be powers of two >= 2 (H=%ld W=%ld)",
+               (long)H, (long)W);
+  DVAE_REQUIRE(Cin == 1 || Cin % 4 == 0, "conv4s2_fwd: Cin must be 1 or a multiple of 4 (Cin=%ld)", (long)Cin);
+  DVAE_REQUIRE(!(Cin == 1 && (in_scale != nullptr || in_act != DVAE_ACT_NONE)),
+               "conv4s2_fwd: no load-time transform on single-channel input");
+  DVAE_REQUIRE(aligned16(x) && aligned16(wp), "conv4s2_fwd: x and wp must be 16-byte aligned");
+  DVAE_REQUIRE(N * H * W * Cin < (1LL << 40), "conv4s2_fwd: tensor too large");
+  ConvArgs g;
+  g.x = x; g.in_scale = in_scale; g.in_shift = in_shift; g.wp = wp; g.y = y; g.stats = stat_partials;
+  g.in_act = in_act; g.H = (int)H; g.W = (int)W; g.lh = ilog2(H / 2); g.lw = ilog2(W / 2);
+  g.Cin = (int)Cin; g.Cout = (int)Cout; g.K = (int)(16 * Cin);
+  g.M = N * (H / 2) * (W / 2);
+  return launch_conv_fwd<0>("conv4s2_fwd", g, 1, ST(stream));
+}
+
+extern "C" int dvae_deconv4s2_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
+                                      const float* wp, float* y, float* stat_partials, int64_t N, int64_t H,
+                                      int64_t W, int64_t Cin, int64_t Cout, dvae_stream_t stream) {
+  DVAE_REQUIRE(N > 0 && Cout > 0, "deconv4s2_fwd: empty");
+  DVAE_REQUIRE(is_pow2(H) && is_pow2(W), "deconv4s2_fwd: H and W must be powers of two (H=%ld W=%ld)", (long)H, (long)W);
+  DVAE_REQUIRE(Cin % 4 == 0, "deconv4s2_fwd: Cin must be a multiple of 4 (Cin=%ld)", (long)Cin);
+  DVAE_REQUIRE(aligned16(x) && aligned16(wp), "deconv4s2_fwd: x and wp must be 16-byte aligned");
+  ConvArgs g;
+  g.x = x; g.in_scale = in_scale; g.in_shift = in_shift; g.wp = wp; g.y = y; g.stats = stat_partials;
+  g.in_act = in_act; g.H = (int)H; g.W = (int)W; g.lh = ilog2(H); g.lw = ilog2(W);
+  g.Cin = (int)Cin; g.Cout = (int)Cout; g.K = (int)(4 * Cin);
+  g.M = N * H * W;
+  return launch_conv_fwd<1>("deconv4s2_fwd", g, 4, ST(stream));
+}
+
+// Host helper used by the Python side through dvae_conv_stat_parts is an upper bound; the exact
+// number of rows written is needed by bn_finalize, so expose it.
+extern "C" int64_t dvae_conv_stat_parts_written(int64_t M_rows_per_phase, int phases) {
+  return conv_parts_written(M_rows_per_phase, phases);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* P;
+  const float* p_scale;
+  const float* p_shift;
+  const float* Q;
+  const float* q_scale;
+  const float* q_shift;
+  float* slab;  // [split][C1][16*C2]
+  int64_t Mtot;  // N*Hs*Ws
+  int p_act, q_act;
+  int Hs, Ws, lh, lw;
+  int C1, C2, NC;  // NC = 16*C2
+  int ktiles_per_split;
+};
+
+template <int V4, int R>
+struct WgradPLoader {
+  const WgradArgs& g;
+  int64_t c0;
+  __device__ __forceinline__ void fetch(int kt, float4 (&r)[V4]) const {
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      int kr, c4;
+      rc_pos<R>(v, kr, c4);
+      const int64_t m = (int64_t)kt * 32 + kr;
+      const int64_t c = c0 + 4 * c4;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < g.Mtot && c < g.C1) {
+        val = *reinterpret_cast<const float4*>(g.P + m * g.C1 + c);
+        val = affine_act4(val, g.p_scale, g.p_shift, (int)c, g.p_act);
+      }
+      r[v] = val;
+    }
+  }
+};
+
+template <int V4, int R, bool C1>
+struct WgradQLoader {
+  const WgradArgs& g;
+  int64_t n0;
+  __device__ __forceinline__ void fetch(int kt, float4 (&r)[V4]) const {
+    const int HQ = 2 * g.Hs, WQ = 2 * g.Ws;
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      int kr, c4;
+      rc_pos<R>(v, kr, c4);
+      const int64_t m = (int64_t)kt * 32 + kr;
+      const int64_t col = n0 + 4 * c4;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < g.Mtot && col < g.NC) {
+        const int b = (int)(m & ((1 << g.lw) - 1));
+        const int a = (int)((m >> g.lw) & ((1 << g.lh) - 1));
+        const int64_t n = m >> (g.lw + g.lh);
+        if (C1) {
+          // single channel: columns are the 16 taps; this chunk is filter row kh = col/4
+          const int kh = (int)(col >> 2);
+          const int hi = 2 * a - 1 + kh;
+          if (hi >= 0 && hi < HQ) {
+            const float* p = g.Q + (n * HQ + hi) * WQ;
+            float t[4];
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+              const int wi = 2 * b - 1 + kw;
+              t[kw] = (wi >= 0 && wi < WQ) ? p[wi] : 0.f;
+            }
+            val = make_float4(t[0], t[1], t[2], t[3]);
+          }
+        } else {
+          const int tap = (int)(col / g.C2);
+          const int c2 = (int)(col - (int64_t)tap * g.C2);
+          const int hi = 2 * a - 1 + (tap >> 2), wi = 2 * b - 1 + (tap & 3);
+          if (hi >= 0 && hi < HQ && wi >= 0 && wi < WQ) {
+            val = *reinterpret_cast<const float4*>(g.Q + ((n * HQ + hi) * WQ + wi) * g.C2 + c2);
+            val = affine_act4(val, g.q_scale, g.q_shift, c2, g.q_act);
+          }
+        }
+      }
+      r[v] = val;
+    }
+  }
+};
+
+template <class T, bool C1>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * T::STAGE_FLOATS];
+  const int64_t m0 = (int64_t)blockIdx.y * T::BM, n0 = (int64_t)blockIdx.x * T::BN;
+  const int ktiles = (int)((g.Mtot + 31) / 32);
+  const int kt_begin = blockIdx.z * g.ktiles_per_split;
+  int kt_end = kt_begin + g.ktiles_per_split;
+  if (kt_end > ktiles) kt_end = ktiles;
+  f32x16 acc[T::TM][T::TN];
+  zero_acc<T>(acc);
+  WgradPLoader<T::A_V4, T::BM> la{g, m0};
+  WgradQLoader<T::B_V4, T::BN, C1> lb{g, n0};
+  gemm_mainloop<T>(la, lb, kt_begin, kt_end, smem, acc);
+  float* dst = g.slab + (int64_t)blockIdx.z * g.C1 * g.NC;
+  for_each_acc<T>(acc, [&](int r, int c, float v) {
+    const int64_t m = m0 + r, n = n0 + c;
+    if (m < g.C1 && n < g.NC) dst[m * g.NC + n] = v;
+  });
+}
+
+// dw[(c1*C2 + c2)*16 + tap] = sum_z slab[z][c1][tap*C2 + c2]
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ slab, int split, float* __restrict__ dw, int64_t C1, int64_t C2) {
+  const int64_t total = C1 * C2 * 16;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t tap = i & 15, c2 = (i >> 4) % C2, c1 = i / (16 * C2);
+    const int64_t src = c1 * (16 * C2) + tap * C2 + c2;
+    float s = 0.f;
+    for (int z = 0; z < split; ++z) s += slab[(int64_t)z * total + src];
+    dw[i] = s;
+  }
+}
+
+struct WgradPlan {
+  int bm;       // 32, 64 or 128
+  int bn;       // 32 or 128
+  int64_t tm, tn;
+  int split, ktiles_per_split;
+};
+
+static WgradPlan wgrad_plan(int64_t Mtot, int64_t C1, int64_t C2) {
+  WgradPlan p;
+  const int64_t NC = 16 * C2;
+  p.bn = NC <= 32 ? 32 : 128;
+  if (p.bn == 32) p.bm = 128;            // 4 waves along M
+  else p.bm = C1 <= 32 ? 32 : (C1 <= 64 ? 64 : 128);
+  p.tm = ceil_div64(C1, p.bm);
+  p.tn = ceil_div64(NC, p.bn);
+  const int64_t ktiles = ceil_div64(Mtot, 32);
+  int64_t s = 1024 / (p.tm * p.tn);
+  if (s > ktiles / 8) s = ktiles / 8;
+  if (s > 512) s = 512;
+  if (s < 1) s = 1;
+  p.ktiles_per_split = (int)ceil_div64(ktiles, s);
+  p.split = (int)ceil_div64(ktiles, p.ktiles_per_split);
+  return p;
+}
+
+extern "C" int64_t dvae_conv_wgrad_ws_floats(int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2) {
+  const WgradPlan p = wgrad_plan(N * Hs * Ws, C1, C2);
+  return (int64_t)p.split * C1 * C2 * 16;
+}
+
+extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, const float* p_shift, int p_act,
+                                      const float* Q, const float* q_scale, const float* q_shift, int q_act,
+                                      float* dw, float* ws, int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2,
+                                      dvae_stream_t stream) {
+  DVAE_REQUIRE(N > 0 && C1 > 0 && C2 > 0, "conv4s2_wgrad: empty");
+  DVAE_REQUIRE(is_pow2(Hs) && is_pow2(Ws), "conv4s2_wgrad: Hs and Ws must be powers of two");
+  DVAE_REQUIRE(C1 % 4 == 0, "conv4s2_wgrad: C1 must be a multiple of 4 (C1=%ld)", (long)C1);
+  DVAE_REQUIRE(C2 == 1 || C2 % 4 == 0, "conv4s2_wgrad: C2 must be 1 or a multiple of 4 (C2=%ld)", (long)C2);
+  DVAE_REQUIRE(!(C2 == 1 && (q_scale != nullptr || q_act != DVAE_ACT_NONE)),
+               "conv4s2_wgrad: no load-time transform on a single-channel Q");
+  DVAE_REQUIRE(aligned16(P) && aligned16(Q) && ws != nullptr, "conv4s2_wgrad: P, Q must be 16-byte aligned, ws non-null");
+  WgradArgs g;
+  g.P = P; g.p_scale = p_scale; g.p_shift = p_shift; g.p_act = p_act;
+  g.Q = Q; g.q_scale = q_scale; g.q_shift = q_shift; g.q_act = q_act;
+  g.slab = ws; g.Mtot = N * Hs * Ws; g.Hs = (int)Hs; g.Ws = (int)Ws; g.lh = ilog2(Hs); g.lw = ilog2(Ws);
+  g.C1 = (int)C1; g.C2 = (int)C2; g.NC = (int)(16 * C2);
+  const WgradPlan p = wgrad_plan(g.Mtot, C1, C2);
+  g.ktiles_per_split = p.ktiles_per_split;
+  const dim3 grid((unsigned)p.tn, (unsigned)p.tm, (unsigned)p.split);
+  hipStream_t s = ST(stream);
+  if (p.bn == 32) {
+    if (C2 == 1) hipLaunchKernelGGL((conv_wgrad_kernel<Tile<128, 32, 4, 1, false, false>, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<Tile<128, 32, 4, 1, false, false>, false>), grid, dim3(256), 0, s, g);
+  } else if (p.bm == 32) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<Tile<32, 128, 1, 4, false, false>, false>), grid, dim3(256), 0, s, g);
+  } else if (p.bm == 64) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<Tile<64, 128, 2, 2, false, false>, false>), grid, dim3(256), 0, s, g);
+  } else {
+    hipLaunchKernelGGL((conv_wgrad_kernel<Tile<128, 128, 2, 2, false, false>, false>), grid, dim3(256), 0, s, g);
+  }
+  DVAE_LAUNCH_CHECK("conv4s2_wgrad");
+  int64_t nb = ceil_div64(C1 * C2 * 16, 256);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float*)ws, p.split, dw, C1, C2);
+  DVAE_LAUNCH_CHECK("conv4s2_wgrad_reduce");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// final decoder layer: ConvTranspose2d(Cin -> 1) + bias + sigmoid.  One output channel, so this is
+// a dot-product kernel bound by the read of x, not a GEMM: one lane per output pixel, 2x2 taps of
+// Cin channels each, the four taps' weights for the pixel's phase held in LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+deconv_final_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
+                    const float* __restrict__ in_shift, int in_act, const float* __restrict__ w,
+                    const float* __restrict__ bias, int out_act, float* __restrict__ y, int64_t total, int H, int W,
+                    int lh, int lw, int Cin) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [4 phases][4 taps][Cin]
+  for (int i = threadIdx.x; i < 16 * Cin; i += 256) {
+    const int ci = i % Cin, tap = (i / Cin) & 3, phase = i / (4 * Cin);
+    const int ph = phase >> 1, pw = phase & 1, th = tap >> 1, tw = tap & 1;
+    const int kh = ph == 0 ? (th == 0 ? 1 : 3) : (th == 0 ? 0 : 2);
+    const int kw = pw == 0 ? (tw == 0 ? 1 : 3) : (tw == 0 ? 0 : 2);
+    wsm[i] = w[(ci * 4 + kh) * 4 + kw];
+  }
+  __syncthreads();
+  const float bv = bias ? bias[0] : 0.f;
+  const int HO = 2 * H, WO = 2 * W;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+    const int wo = (int)(o & (WO - 1));
+    const int ho = (int)((o >> (lw + 1)) & (HO - 1));
+    const int64_t n = o >> (lw + lh + 2);
+    const int ph = ho & 1, pw = wo & 1, a = ho >> 1, b = wo >> 1;
+    const float* wph = wsm + (ph * 2 + pw) * 4 * Cin;
+    float acc = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+      const int hi = a + ph - (tap >> 1), wi = b + pw - (tap & 1);
+      if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
+      const float* px = x + ((n * H + hi) * W + wi) * Cin;
+      const float* wt = wph + tap * Cin;
+      for (int ci = 0; ci < Cin; ci += 4) {
+        float4 v = *reinterpret_cast<const float4*>(px + ci);
+        v = affine_act4(v, in_scale, in_shift, ci, in_act);
+        const float4 ww = *reinterpret_cast<const float4*>(wt + ci);
+        acc = fmaf(v.x, ww.x, acc);
+        acc = fmaf(v.y, ww.y, acc);
+        acc = fmaf(v.z, ww.z, acc);
+        acc = fmaf(v.w, ww.w, acc);
+      }
+    }
+    acc += bv;
+    if (out_act == DVAE_ACT_SIGMOID) acc = 1.f / (1.f + expf(-acc));
+    y[o] = acc;
+  }
+}
+
+extern "C" int dvae_deconv4s2_final_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
+                                            const float* w, const float* bias, int out_act, float* y, int64_t N,
+                                            int64_t H, int64_t W, int64_t Cin, dvae_stream_t stream) {
+  DVAE_REQUIRE(N > 0, "deconv4s2_final_fwd: empty");
+  DVAE_REQUIRE(is_pow2(H) && is_pow2(W), "deconv4s2_final_fwd: H and W must be powers of two");
+  DVAE_REQUIRE(Cin % 4 == 0 && Cin <= 1024, "deconv4s2_final_fwd: Cin must be a multiple of 4, at most 1024 (Cin=%ld)", (long)Cin);
+  DVAE_REQUIRE(aligned16(x), "deconv4s2_final_fwd: x must be 16-byte aligned");
+  const int64_t total = N * 4 * H * W;
+  int64_t nb = ceil_div64(total, 256);
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(deconv_final_kernel, dim3((unsigned)nb), dim3(256), (size_t)(16 * Cin * 4), ST(stream), x, in_scale,
+                     in_shift, in_act, w, bias, out_act, y, total, (int)H, (int)W, ilog2(H), ilog2(W), (int)Cin);
+  DVAE_LAUNCH_CHECK("deconv4s2_final_fwd");
+  return 0;
+}

@@ -1,0 +1,756 @@
+// HBM-bound kernels of the video-VAE hot path: content/motion split, losses, BatchNorm glue,
+// activation backward.  All fp32 in memory; reductions accumulate in fp64 and use a fixed
+// two-stage order (per-workgroup partials, then one workgroup), so results are run-to-run stable.
+#include "common.h"
+#include "../../include/dvae_hip.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void dvae_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* dvae_last_error(void) { return g_err; }
+extern "C" int dvae_version(void) { return 1; }
+
+#define ST(s) ((hipStream_t)(s))
+
+// ------------------------------------------------------------------------------------------------
+// temporal mean + frame difference: one pass over the clip, 16 B per lane, T loads in flight.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+split_mean_diff_kernel(const float4* __restrict__ video, float4* __restrict__ mean,
+                       float4* __restrict__ diff, int64_t total, int T, int64_t P4) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t b = idx / P4, p = idx - b * P4;
+  const float4* src = video + b * T * P4 + p;
+  float4* d = diff + b * (T - 1) * P4 + p;
+  float4 prev = src[0];
+  float4 sum = prev;
+#pragma unroll 4
+  for (int t = 1; t < T; ++t) {
+    const float4 cur = src[(int64_t)t * P4];
+    d[(int64_t)(t - 1) * P4] = make_float4(cur.x - prev.x, cur.y - prev.y, cur.z - prev.z, cur.w - prev.w);
+    sum.x += cur.x; sum.y += cur.y; sum.z += cur.z; sum.w += cur.w;
+    prev = cur;
+  }
+  const float inv = (float)T;
+  mean[idx] = make_float4(sum.x / inv, sum.y / inv, sum.z / inv, sum.w / inv);
+}
+
+extern "C" int dvae_split_mean_diff_f32(const float* video, float* mean, float* diff, int64_t B, int64_t T,
+                                        int64_t P, dvae_stream_t stream) {
+  DVAE_REQUIRE(B > 0 && T >= 1 && P > 0 && P % 4 == 0, "split_mean_diff: need B>0, T>=1, P%%4==0 (B=%ld T=%ld P=%ld)",
+               (long)B, (long)T, (long)P);
+  const int64_t total = B * (P / 4);
+  hipLaunchKernelGGL(split_mean_diff_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, ST(stream),
+                     (const float4*)video, (float4*)mean, (float4*)diff, total, (int)T, P / 4);
+  DVAE_LAUNCH_CHECK("split_mean_diff");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reconstruction loss
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float recon_elem(float r, float x, int kind) {
+  if (kind == 0) {
+    const float e = r - x;
+    return e * e;
+  }
+  const float lp = fmaxf(logf(r), -100.f);
+  const float lq = fmaxf(logf(1.f - r), -100.f);
+  return -(x * lp + (1.f - x) * lq);
+}
+
+#define RL_MAX_BLOCKS 2048
+
+__global__ void __launch_bounds__(256)
+recon_loss_fwd_kernel(const float4* __restrict__ recon, const float4* __restrict__ target,
+                      double* __restrict__ partials, int64_t total, int T, int64_t P4, int kind, int with_temporal) {
+  __shared__ double red[4];
+  double s_rec = 0.0, s_tmp = 0.0;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t b = idx / P4, p = idx - b * P4;
+    const float4* r = recon + b * T * P4 + p;
+    const float4* x = target + b * T * P4 + p;
+    float4 rp = r[0], xp = x[0];
+    float acc = recon_elem(rp.x, xp.x, kind) + recon_elem(rp.y, xp.y, kind) + recon_elem(rp.z, xp.z, kind) +
+                recon_elem(rp.w, xp.w, kind);
+    float acct = 0.f;
+    for (int t = 1; t < T; ++t) {
+      const float4 rc = r[(int64_t)t * P4], xc = x[(int64_t)t * P4];
+      acc += recon_elem(rc.x, xc.x, kind) + recon_elem(rc.y, xc.y, kind) + recon_elem(rc.z, xc.z, kind) +
+             recon_elem(rc.w, xc.w, kind);
+      if (with_temporal) {
+        const float d0 = (rc.x - rp.x) - (xc.x - xp.x), d1 = (rc.y - rp.y) - (xc.y - xp.y);
+        const float d2 = (rc.z - rp.z) - (xc.z - xp.z), d3 = (rc.w - rp.w) - (xc.w - xp.w);
+        acct += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+      }
+      rp = rc;
+      xp = xc;
+    }
+    s_rec += (double)acc;
+    s_tmp += (double)acct;
+  }
+  const double a = block_sum_256(s_rec, red);
+  const double b2 = block_sum_256(s_tmp, red);
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x] = a;
+    partials[2 * blockIdx.x + 1] = b2;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+recon_loss_finalize_kernel(const double* __restrict__ partials, int nparts, float* __restrict__ out, double B,
+                           double T, double P) {
+  __shared__ double red[4];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) {
+    a += partials[2 * i];
+    b += partials[2 * i + 1];
+  }
+  a = block_sum_256(a, red);
+  b = block_sum_256(b, red);
+  if (threadIdx.x == 0) {
+    const float per_pixel = (float)(a / (B * T * P));
+    out[0] = per_pixel;
+    out[1] = per_pixel * (float)(T * P);
+    out[2] = T > 1 ? (float)(b / (B * (T - 1) * P)) * (float)((T - 1) * P) : 0.f;
+  }
+}
+
+static int recon_blocks(int64_t B, int64_t P) {
+  int64_t n = ceil_div64(B * (P / 4), 256);
+  return (int)(n < RL_MAX_BLOCKS ? n : RL_MAX_BLOCKS);
+}
+
+extern "C" int64_t dvae_recon_loss_ws_floats(int64_t B, int64_t T, int64_t P) {
+  (void)T;
+  return 4 * (int64_t)RL_MAX_BLOCKS + 4;  // doubles, 2 per block
+}
+
+extern "C" int dvae_recon_loss_fwd_f32(const float* recon, const float* target, float* out, float* ws, int64_t B,
+                                       int64_t T, int64_t P, int kind, int with_temporal, dvae_stream_t stream) {
+  DVAE_REQUIRE(B > 0 && T >= 1 && P > 0 && P % 4 == 0, "recon_loss_fwd: need P%%4==0");
+  DVAE_REQUIRE(kind == 0 || kind == 1, "recon_loss_fwd: kind must be 0 (mse) or 1 (bce)");
+  DVAE_REQUIRE(((uintptr_t)ws & 7) == 0, "recon_loss_fwd: workspace must be 8-byte aligned");
+  const int nb = recon_blocks(B, P);
+  hipLaunchKernelGGL(recon_loss_fwd_kernel, dim3(nb), dim3(256), 0, ST(stream), (const float4*)recon,
+                     (const float4*)target, (double*)ws, B * (P / 4), (int)T, P / 4, kind, with_temporal);
+  DVAE_LAUNCH_CHECK("recon_loss_fwd");
+  hipLaunchKernelGGL(recon_loss_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, nb, out,
+                     (double)B, (double)T, (double)P);
+  DVAE_LAUNCH_CHECK("recon_loss_finalize");
+  return 0;
+}
+
+__device__ __forceinline__ float recon_grad_elem(float r, float x, int kind) {
+  if (kind == 0) return 2.f * (r - x);
+  // F.binary_cross_entropy backward: (r - x) / max((1 - r) * r, 1e-12)
+  return (r - x) / fmaxf((1.f - r) * r, 1e-12f);
+}
+
+__global__ void __launch_bounds__(256)
+recon_loss_bwd_kernel(const float4* __restrict__ recon, const float4* __restrict__ target,
+                      const float* __restrict__ gscale, float4* __restrict__ drecon, int64_t total, int T,
+                      int64_t P4, int kind, float w_rec, float w_tmp) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const float g = gscale ? gscale[0] : 1.f;
+  const float wr = w_rec * g, wt = w_tmp * g;
+  const int64_t b = idx / P4, p = idx - b * P4;
+  const float4* r = recon + b * T * P4 + p;
+  const float4* x = target + b * T * P4 + p;
+  float4* d = drecon + b * T * P4 + p;
+  float4 rc = r[0], xc = x[0];
+  float4 dprev = make_float4(0.f, 0.f, 0.f, 0.f);  // (dr - dx) between t-1 and t
+  for (int t = 0; t < T; ++t) {
+    float4 rn = rc, xn = xc;
+    float4 dnext = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t + 1 < T) {
+      rn = r[(int64_t)(t + 1) * P4];
+      xn = x[(int64_t)(t + 1) * P4];
+      if (wt != 0.f)
+        dnext = make_float4((rn.x - rc.x) - (xn.x - xc.x), (rn.y - rc.y) - (xn.y - xc.y),
+                            (rn.z - rc.z) - (xn.z - xc.z), (rn.w - rc.w) - (xn.w - xc.w));
+    }
+    float4 o;
+    o.x = wr * recon_grad_elem(rc.x, xc.x, kind) + wt * (dprev.x - dnext.x);
+    o.y = wr * recon_grad_elem(rc.y, xc.y, kind) + wt * (dprev.y - dnext.y);
+    o.z = wr * recon_grad_elem(rc.z, xc.z, kind) + wt * (dprev.z - dnext.z);
+    o.w = wr * recon_grad_elem(rc.w, xc.w, kind) + wt * (dprev.w - dnext.w);
+    d[(int64_t)t * P4] = o;
+    dprev = dnext;
+    rc = rn;
+    xc = xn;
+  }
+}
+
+extern "C" int dvae_recon_loss_bwd_f32(const float* recon, const float* target, const float* gscale, float* drecon,
+                                       int64_t B, int64_t T, int64_t P, int kind, float temporal_weight,
+                                       dvae_stream_t stream) {
+  DVAE_REQUIRE(B > 0 && T >= 1 && P > 0 && P % 4 == 0, "recon_loss_bwd: need P%%4==0");
+  DVAE_REQUIRE(kind == 0 || kind == 1, "recon_loss_bwd: kind must be 0 (mse) or 1 (bce)");
+  const int64_t total = B * (P / 4);
+  // out[1] = sum(l)/B ; out[2] = sum(d^2)/B
+  const float w_rec = 1.f / (float)B;
+  const float w_tmp = (T > 1) ? 2.f * temporal_weight / (float)B : 0.f;
+  hipLaunchKernelGGL(recon_loss_bwd_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, ST(stream),
+                     (const float4*)recon, (const float4*)target, gscale, (float4*)drecon, total, (int)T, P / 4,
+                     kind, w_rec, w_tmp);
+  DVAE_LAUNCH_CHECK("recon_loss_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reparameterisation and KL (tiny tensors: [B, latent])
+// ------------------------------------------------------------------------------------------------
+__global__ void reparam_fwd_kernel(const float* mu, const float* logvar, const float* eps, float* z, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) z[i] = mu[i] + eps[i] * expf(0.5f * logvar[i]);
+}
+
+__global__ void reparam_bwd_kernel(const float* dz, const float* logvar, const float* eps, float* dmu,
+                                   float* dlogvar, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const float g = dz[i];
+    dmu[i] = g;
+    dlogvar[i] = g * eps[i] * 0.5f * expf(0.5f * logvar[i]);
+  }
+}
+
+extern "C" int dvae_reparam_fwd_f32(const float* mu, const float* logvar, const float* eps, float* z, int64_t n,
+                                    dvae_stream_t stream) {
+  DVAE_REQUIRE(n > 0, "reparam_fwd: empty");
+  hipLaunchKernelGGL(reparam_fwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ST(stream), mu, logvar,
+                     eps, z, n);
+  DVAE_LAUNCH_CHECK("reparam_fwd");
+  return 0;
+}
+
+extern "C" int dvae_reparam_bwd_f32(const float* dz, const float* logvar, const float* eps, float* dmu,
+                                    float* dlogvar, int64_t n, dvae_stream_t stream) {
+  DVAE_REQUIRE(n > 0, "reparam_bwd: empty");
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ST(stream), dz, logvar,
+                     eps, dmu, dlogvar, n);
+  DVAE_LAUNCH_CHECK("reparam_bwd");
+  return 0;
+}
+
+__global__ void __launch_bounds__(256)
+kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, float* __restrict__ out, int64_t B,
+              int64_t D, float free_bits) {
+  __shared__ double red[4];
+  double s_floor = 0.0, s_raw = 0.0;
+  const int64_t n = B * D;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const float m = mu[i], lv = logvar[i];
+    const float kl = -0.5f * (1.f + lv - m * m - expf(lv));
+    s_raw += (double)kl;
+    s_floor += (double)((free_bits > 0.f) ? fmaxf(kl, free_bits) : kl);
+  }
+  s_floor = block_sum_256(s_floor, red);
+  s_raw = block_sum_256(s_raw, red);
+  if (threadIdx.x == 0) {
+    out[0] = (float)(s_floor / (double)B);
+    out[1] = (float)(s_raw / (double)B);
+    out[2] = (float)(s_floor / (double)n);
+  }
+}
+
+__global__ void kl_bwd_kernel(const float* mu, const float* logvar, const float* gscale, float coef, float* dmu,
+                              float* dlogvar, int64_t n, float free_bits) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float c = coef * (gscale ? gscale[0] : 1.f);
+  const float m = mu[i], lv = logvar[i];
+  const float e = expf(lv);
+  float gm = c * m, gl = c * 0.5f * (e - 1.f);
+  if (free_bits > 0.f) {
+    const float kl = -0.5f * (1.f + lv - m * m - e);
+    if (!(kl > free_bits)) {  // the floor is active: maximum() passes no gradient to kl
+      gm = 0.f;
+      gl = 0.f;
+    }
+  }
+  dmu[i] = gm;
+  dlogvar[i] = gl;
+}
+
+extern "C" int dvae_kl_fwd_f32(const float* mu, const float* logvar, float* out, int64_t B, int64_t D,
+                               float free_bits, dvae_stream_t stream) {
+  DVAE_REQUIRE(B > 0 && D > 0, "kl_fwd: empty");
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3(1), dim3(256), 0, ST(stream), mu, logvar, out, B, D, free_bits);
+  DVAE_LAUNCH_CHECK("kl_fwd");
+  return 0;
+}
+
+extern "C" int dvae_kl_bwd_f32(const float* mu, const float* logvar, const float* gscale, float coef, float* dmu,
+                               float* dlogvar, int64_t B, int64_t D, float free_bits, dvae_stream_t stream) {
+  DVAE_REQUIRE(B > 0 && D > 0, "kl_bwd: empty");
+  const int64_t n = B * D;
+  hipLaunchKernelGGL(kl_bwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ST(stream), mu, logvar,
+                     gscale, coef / (float)B, dmu, dlogvar, n, free_bits);
+  DVAE_LAUNCH_CHECK("kl_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// independence term.  ws layout: corr[Dc*Dm] | mean_c[Dc] | inv_c[Dc] | mean_m[Dm] | inv_m[Dm] | part[Dc]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+indep_stats_kernel(const float* __restrict__ z, float* __restrict__ mean, float* __restrict__ inv, int64_t B,
+                   int64_t D) {
+  // one workgroup per column
+  __shared__ double red[4];
+  const int64_t j = blockIdx.x;
+  double s = 0.0;
+  for (int64_t b = threadIdx.x; b < B; b += 256) s += (double)z[b * D + j];
+  s = block_sum_256(s, red);
+  __shared__ double mu_s;
+  if (threadIdx.x == 0) mu_s = s / (double)B;
+  __syncthreads();
+  const double mu = mu_s;
+  double q = 0.0;
+  for (int64_t b = threadIdx.x; b < B; b += 256) {
+    const double d = (double)z[b * D + j] - mu;
+    q += d * d;
+  }
+  q = block_sum_256(q, red);
+  if (threadIdx.x == 0) {
+    const float sd = (float)sqrt(q / (double)(B > 1 ? B - 1 : 1));
+    mean[j] = (float)mu;
+    inv[j] = 1.f / (sd + 1e-8f);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+indep_corr_kernel(const float* __restrict__ zc, const float* __restrict__ zm, float* __restrict__ ws, int64_t B,
+                  int64_t Dc, int64_t Dm) {
+  // one workgroup per content column i; threads over motion columns j
+  __shared__ double red[4];
+  float* corr = ws;
+  const float* mean_c = ws + Dc * Dm;
+  const float* inv_c = mean_c + Dc;
+  const float* mean_m = inv_c + Dc;
+  const float* inv_m = mean_m + Dm;
+  float* part = const_cast<float*>(inv_m) + Dm;
+  const int64_t i = blockIdx.x;
+  const float mc = mean_c[i], ic = inv_c[i];
+  double sq = 0.0;
+  for (int64_t j = threadIdx.x; j < Dm; j += 256) {
+    const float mm = mean_m[j], im = inv_m[j];
+    float acc = 0.f;
+    for (int64_t b = 0; b < B; ++b) acc += ((zc[b * Dc + i] - mc) * ic) * ((zm[b * Dm + j] - mm) * im);
+    const float c = acc / (float)B;
+    corr[i * Dm + j] = c;
+    sq += (double)c * (double)c;
+  }
+  sq = block_sum_256(sq, red);
+  if (threadIdx.x == 0) part[i] = (float)sq;
+}
+
+__global__ void __launch_bounds__(256)
+indep_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t Dc, int64_t Dm) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < Dc; i += 256) s += (double)part[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] = (float)(s / (double)(Dc * Dm));
+}
+
+// gradient for one side.  X is the side being differentiated [B,Dx], Y the other [B,Dy];
+// corr is indexed corr[ix*sx + iy*sy].
+__global__ void __launch_bounds__(256)
+indep_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ corr,
+                 int64_t sx, int64_t sy, const float* __restrict__ mean_x, const float* __restrict__ inv_x,
+                 const float* __restrict__ mean_y, const float* __restrict__ inv_y,
+                 const float* __restrict__ gscale, float coef, float* __restrict__ dX, int64_t B, int64_t Dx,
+                 int64_t Dy) {
+  // one workgroup per column i of X
+  extern __shared__ float gx_s[];  // B floats
+  __shared__ double red[4];
+  const int64_t i = blockIdx.x;
+  const float g = coef * (gscale ? gscale[0] : 1.f);
+  const float mx = mean_x[i], ix = inv_x[i];
+  const float gfac = 2.f / (float)(Dx * Dy) / (float)B;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t b = threadIdx.x; b < B; b += 256) {
+    float acc = 0.f;
+    for (int64_t j = 0; j < Dy; ++j) acc += corr[i * sx + j * sy] * ((Y[b * Dy + j] - mean_y[j]) * inv_y[j]);
+    const float gx = acc * gfac;  // dL/d xtilde_bi
+    gx_s[b] = gx;
+    s1 += (double)gx;
+    s2 += (double)gx * (double)(X[b * Dx + i] - mx);
+  }
+  s1 = block_sum_256(s1, red);
+  __shared__ double s1_s, s2_s;
+  if (threadIdx.x == 0) s1_s = s1;
+  s2 = block_sum_256(s2, red);
+  if (threadIdx.x == 0) s2_s = s2;
+  __syncthreads();
+  const float gbar = (float)(s1_s / (double)B);
+  // std s = 1/ix - 1e-8 ; d s / d x_b = (x_b - mu) / ((B-1) s)
+  const float sd = 1.f / ix - 1e-8f;
+  const float k2 = (B > 1 && sd > 0.f) ? (float)s2_s * ix * ix / ((float)(B - 1) * sd) : 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += 256) {
+    const float v = (gx_s[b] - gbar) * ix - (X[b * Dx + i] - mx) * k2;
+    dX[b * Dx + i] = g * v;
+  }
+}
+
+extern "C" int64_t dvae_indep_ws_floats(int64_t Dc, int64_t Dm) { return Dc * Dm + 3 * Dc + 2 * Dm; }
+
+extern "C" int dvae_indep_fwd_f32(const float* zc, const float* zm, float* out, float* ws, int64_t B, int64_t Dc,
+                                  int64_t Dm, dvae_stream_t stream) {
+  DVAE_REQUIRE(B > 0 && Dc > 0 && Dm > 0, "indep_fwd: empty");
+  float* mean_c = ws + Dc * Dm;
+  float* inv_c = mean_c + Dc;
+  float* mean_m = inv_c + Dc;
+  float* inv_m = mean_m + Dm;
+  float* part = inv_m + Dm;
+  hipLaunchKernelGGL(indep_stats_kernel, dim3((unsigned)Dc), dim3(256), 0, ST(stream), zc, mean_c, inv_c, B, Dc);
+  hipLaunchKernelGGL(indep_stats_kernel, dim3((unsigned)Dm), dim3(256), 0, ST(stream), zm, mean_m, inv_m, B, Dm);
+  hipLaunchKernelGGL(indep_corr_kernel, dim3((unsigned)Dc), dim3(256), 0, ST(stream), zc, zm, ws, B, Dc, Dm);
+  hipLaunchKernelGGL(indep_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), part, out, Dc, Dm);
+  DVAE_LAUNCH_CHECK("indep_fwd");
+  return 0;
+}
+
+extern "C" int dvae_indep_bwd_f32(const float* zc, const float* zm, const float* ws, const float* gscale, float coef,
+                                  float* dzc, float* dzm, int64_t B, int64_t Dc, int64_t Dm, dvae_stream_t stream) {
+  DVAE_REQUIRE(B > 0 && Dc > 0 && Dm > 0, "indep_bwd: empty");
+  DVAE_REQUIRE(B * 4 <= 64 * 1024, "indep_bwd: batch %ld too large for the LDS staging buffer", (long)B);
+  const float* corr = ws;
+  const float* mean_c = ws + Dc * Dm;
+  const float* inv_c = mean_c + Dc;
+  const float* mean_m = inv_c + Dc;
+  const float* inv_m = mean_m + Dm;
+  hipLaunchKernelGGL(indep_bwd_kernel, dim3((unsigned)Dc), dim3(256), (size_t)B * 4, ST(stream), zc, zm, corr, Dm,
+                     (int64_t)1, mean_c, inv_c, mean_m, inv_m, gscale, coef, dzc, B, Dc, Dm);
+  hipLaunchKernelGGL(indep_bwd_kernel, dim3((unsigned)Dm), dim3(256), (size_t)B * 4, ST(stream), zm, zc, corr,
+                     (int64_t)1, Dm, mean_m, inv_m, mean_c, inv_c, gscale, coef, dzm, B, Dm, Dc);
+  DVAE_LAUNCH_CHECK("indep_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm glue
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+bn_finalize_kernel(const float* __restrict__ partials, int64_t nparts, double M, int64_t C,
+                   const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                   float* running_var, int64_t* nbt, float momentum, float eps, float* scale, float* shift,
+                   float* mean_out, float* invstd_out) {
+  __shared__ double red[4];
+  const int64_t c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t p = threadIdx.x; p < nparts; p += 256) {
+    s1 += (double)partials[(p * 2) * C + c];
+    s2 += (double)partials[(p * 2 + 1) * C + c];
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  if (threadIdx.x == 0) {
+    const double mean = s1 / M;
+    double var = s2 / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((double)gamma[c] * invstd);
+    scale[c] = sc;
+    shift[c] = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
+    mean_out[c] = (float)mean;
+    invstd_out[c] = (float)invstd;
+    if (running_mean) {
+      const double unb = M > 1.0 ? var * (M / (M - 1.0)) : var;
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+    if (nbt && c == 0) nbt[0] += 1;
+  }
+}
+
+extern "C" int dvae_bn_finalize_f32(const float* partials, int64_t nparts, int64_t M, int64_t C, const float* gamma,
+                                    const float* beta, float* running_mean, float* running_var,
+                                    int64_t* num_batches_tracked, float momentum, float eps, float* scale,
+                                    float* shift, float* mean, float* invstd, dvae_stream_t stream) {
+  DVAE_REQUIRE(nparts > 0 && M > 0 && C > 0, "bn_finalize: empty");
+  DVAE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running buffers come in pairs");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), partials, nparts, (double)M, C,
+                     gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean,
+                     invstd);
+  DVAE_LAUNCH_CHECK("bn_finalize");
+  return 0;
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, float* scale, float* shift, int64_t C) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float inv = 1.f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * inv;
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+extern "C" int dvae_bn_eval_affine_f32(const float* gamma, const float* beta, const float* running_mean,
+                                       const float* running_var, float eps, float* scale, float* shift, int64_t C,
+                                       dvae_stream_t stream) {
+  DVAE_REQUIRE(C > 0, "bn_eval_affine: empty");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((unsigned)ceil_div64(C, 256)), dim3(256), 0, ST(stream), gamma, beta,
+                     running_mean, running_var, eps, scale, shift, C);
+  DVAE_LAUNCH_CHECK("bn_eval_affine");
+  return 0;
+}
+
+__global__ void __launch_bounds__(256)
+affine_act_kernel(const float4* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                  int act, float4* __restrict__ out, int64_t total4, int C4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    out[i] = affine_act4(x[i], scale, shift, c, act);
+  }
+}
+
+extern "C" int dvae_affine_act_f32(const float* x, const float* scale, const float* shift, int act, float* out,
+                                   int64_t M, int64_t C, dvae_stream_t stream) {
+  DVAE_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "affine_act: need C%%4==0");
+  const int64_t total4 = M * C / 4;
+  int64_t nb = ceil_div64(total4, 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(affine_act_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), (const float4*)x, scale, shift,
+                     act, (float4*)out, total4, (int)(C / 4));
+  DVAE_LAUNCH_CHECK("affine_act");
+  return 0;
+}
+
+// ---- column sums over [M, C] with an element transform ------------------------------------------
+// Thread layout: TX column groups (4 columns each) x TY rows; grid.y tiles the column groups,
+// grid.x strides the rows.  Each workgroup writes one row of partials[grid.x][NV][C].
+#define CS_MAX_ROWBLOCKS 1024
+
+struct ColsumGeom {
+  int tx, ty, gy;
+  int64_t gx;
+};
+
+static ColsumGeom colsum_geom(int64_t M, int64_t C) {
+  ColsumGeom g;
+  const int64_t c4 = C / 4;
+  int tx = 1;
+  while (tx < c4 && tx < 256) tx <<= 1;
+  g.tx = tx;
+  g.ty = 256 / tx;
+  g.gy = (int)ceil_div64(c4, tx);
+  int64_t gx = ceil_div64(M, (int64_t)g.ty * 8);
+  if (gx > CS_MAX_ROWBLOCKS) gx = CS_MAX_ROWBLOCKS;
+  if (gx < 1) gx = 1;
+  g.gx = gx;
+  return g;
+}
+
+extern "C" int64_t dvae_colsum_ws_floats(int64_t M, int64_t C) {
+  (void)M;
+  return (int64_t)CS_MAX_ROWBLOCKS * C + 2 * C;
+}
+
+// MODE 0: BN backward stats: v1 = dz, v2 = dz * xhat   (NV = 2)
+// MODE 1: bias/activation backward: dpre = dout*act'(out) written in place, v1 = dpre (NV = 1)
+template <int MODE>
+__global__ void __launch_bounds__(256)
+colsum_kernel(float* __restrict__ du, const float* __restrict__ y, const float* __restrict__ scale,
+              const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+              int act, float* __restrict__ partials, int64_t M, int64_t C, int tx, int ty) {
+  constexpr int NV = MODE == 0 ? 2 : 1;
+  __shared__ float red[256 * 4 * NV];
+  const int cx = threadIdx.x % tx, ry = threadIdx.x / tx;
+  const int64_t c4 = (int64_t)blockIdx.y * tx + cx;
+  const bool col_ok = c4 * 4 < C;
+  const int64_t c = c4 * 4;
+  float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f), mu = sh, is = sc;
+  if (MODE == 0 && col_ok) {
+    sc = *reinterpret_cast<const float4*>(scale + c);
+    sh = *reinterpret_cast<const float4*>(shift + c);
+    mu = *reinterpret_cast<const float4*>(mean + c);
+    is = *reinterpret_cast<const float4*>(invstd + c);
+  }
+  if (col_ok) {
+    for (int64_t r = (int64_t)blockIdx.x * ty + ry; r < M; r += (int64_t)gridDim.x * ty) {
+      float4 g = *reinterpret_cast<const float4*>(du + r * C + c);
+      if (MODE == 0) {
+        const float4 yv = *reinterpret_cast<const float4*>(y + r * C + c);
+        const float z0 = fmaf(yv.x, sc.x, sh.x), z1 = fmaf(yv.y, sc.y, sh.y), z2 = fmaf(yv.z, sc.z, sh.z),
+                    z3 = fmaf(yv.w, sc.w, sh.w);
+        const float d0 = z0 > 0.f ? g.x : g.x * LRELU_SLOPE, d1 = z1 > 0.f ? g.y : g.y * LRELU_SLOPE,
+                    d2 = z2 > 0.f ? g.z : g.z * LRELU_SLOPE, d3 = z3 > 0.f ? g.w : g.w * LRELU_SLOPE;
+        a1[0] += d0; a1[1] += d1; a1[2] += d2; a1[3] += d3;
+        a2[0] += d0 * ((yv.x - mu.x) * is.x);
+        a2[1] += d1 * ((yv.y - mu.y) * is.y);
+        a2[2] += d2 * ((yv.z - mu.z) * is.z);
+        a2[3] += d3 * ((yv.w - mu.w) * is.w);
+      } else {
+        if (act == DVAE_ACT_LRELU) {
+          const float4 o = *reinterpret_cast<const float4*>(y + r * C + c);
+          g.x = o.x > 0.f ? g.x : g.x * LRELU_SLOPE;
+          g.y = o.y > 0.f ? g.y : g.y * LRELU_SLOPE;
+          g.z = o.z > 0.f ? g.z : g.z * LRELU_SLOPE;
+          g.w = o.w > 0.f ? g.w : g.w * LRELU_SLOPE;
+          *reinterpret_cast<float4*>(du + r * C + c) = g;
+        }
+        a1[0] += g.x; a1[1] += g.y; a1[2] += g.z; a1[3] += g.w;
+      }
+    }
+  }
+  // reduce over ry
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    red[(threadIdx.x * NV + 0) * 4 + k] = a1[k];
+    if (NV == 2) red[(threadIdx.x * NV + 1) * 4 + k] = a2[k];
+  }
+  __syncthreads();
+  if (ry == 0 && col_ok) {
+    for (int v = 0; v < NV; ++v) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < ty; ++j) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += red[(((j * tx) + cx) * NV + v) * 4 + k];
+      }
+      float* dst = partials + ((int64_t)blockIdx.x * NV + v) * C + c;
+      *reinterpret_cast<float4*>(dst) = make_float4(s[0], s[1], s[2], s[3]);
+    }
+  }
+}
+
+// sums partials[nparts][NV][C] -> out_v[C]; optional BN-backward constants
+__global__ void __launch_bounds__(256)
+colsum_finalize_kernel(const float* __restrict__ partials, int64_t nparts, int NV, int64_t C, float* out0,
+                       float* out1) {
+  __shared__ double red[4];
+  const int64_t c = blockIdx.x;
+  for (int v = 0; v < NV; ++v) {
+    double s = 0.0;
+    for (int64_t p = threadIdx.x; p < nparts; p += 256) s += (double)partials[(p * NV + v) * C + c];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) {
+      float* o = v == 0 ? out0 : out1;
+      if (o) o[c] = (float)s;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_kernel(float4* __restrict__ du, const float4* __restrict__ y, const float* __restrict__ scale,
+                    const float* __restrict__ shift, const float* __restrict__ mean,
+                    const float* __restrict__ invstd, const float* __restrict__ dbeta,
+                    const float* __restrict__ dgamma, float invM, int64_t total4, int C4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+    const float4 db = *reinterpret_cast<const float4*>(dbeta + c);
+    const float4 dg = *reinterpret_cast<const float4*>(dgamma + c);
+    const float4 g = du[i];
+    const float4 yv = y[i];
+    float4 o;
+#define BN_ONE(f)                                                         \
+  {                                                                       \
+    const float z = fmaf(yv.f, sc.f, sh.f);                               \
+    const float dz = z > 0.f ? g.f : g.f * LRELU_SLOPE;                   \
+    const float xh = (yv.f - mu.f) * is.f;                                \
+    o.f = sc.f * (dz - db.f * invM - xh * (dg.f * invM));                 \
+  }
+    BN_ONE(x) BN_ONE(y) BN_ONE(z) BN_ONE(w)
+#undef BN_ONE
+    du[i] = o;
+  }
+}
+
+extern "C" int dvae_bn_bwd_f32(float* du, const float* y, const float* scale, const float* shift, const float* mean,
+                               const float* invstd, const float* gamma, float* dgamma, float* dbeta, float* ws,
+                               int64_t M, int64_t C, dvae_stream_t stream) {
+  (void)gamma;  // scale already equals gamma*invstd
+  DVAE_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd: need C%%4==0 (C=%ld)", (long)C);
+  const ColsumGeom g = colsum_geom(M, C);
+  hipLaunchKernelGGL(colsum_kernel<0>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), du, y, scale, shift, mean,
+                     invstd, 0, ws, M, C, g.tx, g.ty);
+  DVAE_LAUNCH_CHECK("bn_bwd_reduce");
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), (const float*)ws, g.gx, 2, C,
+                     dbeta, dgamma);
+  DVAE_LAUNCH_CHECK("bn_bwd_finalize");
+  const int64_t total4 = M * C / 4;
+  int64_t nb = ceil_div64(total4, 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), (float4*)du, (const float4*)y,
+                     scale, shift, mean, invstd, (const float*)dbeta, (const float*)dgamma, 1.f / (float)M, total4,
+                     (int)(C / 4));
+  DVAE_LAUNCH_CHECK("bn_bwd_apply");
+  return 0;
+}
+
+extern "C" int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, float* dbias, float* ws, int64_t M,
+                                     int64_t N, dvae_stream_t stream) {
+  DVAE_REQUIRE(M > 0 && N > 0 && N % 4 == 0, "bias_act_bwd: need N%%4==0 (N=%ld)", (long)N);
+  DVAE_REQUIRE(act == DVAE_ACT_NONE || act == DVAE_ACT_LRELU, "bias_act_bwd: unsupported activation %d", act);
+  if (act == DVAE_ACT_NONE && dbias == nullptr) return 0;
+  const ColsumGeom g = colsum_geom(M, N);
+  hipLaunchKernelGGL(colsum_kernel<1>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), dout, out,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, ws,
+                     M, N, g.tx, g.ty);
+  DVAE_LAUNCH_CHECK("bias_act_bwd");
+  if (dbias) {
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)N), dim3(256), 0, ST(stream), (const float*)ws, g.gx, 1,
+                       N, dbias, (float*)nullptr);
+    DVAE_LAUNCH_CHECK("bias_act_bwd_finalize");
+  }
+  return 0;
+}
+
+__global__ void __launch_bounds__(256)
+sigmoid_bwd_kernel(const float* __restrict__ dr, const float* __restrict__ r, float* __restrict__ dl,
+                   double* __restrict__ partials, int64_t n) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float rv = r[i];
+    const float v = dr[i] * rv * (1.f - rv);
+    dl[i] = v;
+    s += (double)v;
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256)
+sum_partials_kernel(const double* __restrict__ partials, int n, float* out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] = (float)s;
+}
+
+extern "C" int dvae_sigmoid_bwd_f32(const float* drecon, const float* recon, float* dlogit, float* dbias, float* ws,
+                                    int64_t n, dvae_stream_t stream) {
+  DVAE_REQUIRE(n > 0, "sigmoid_bwd: empty");
+  DVAE_REQUIRE(((uintptr_t)ws & 7) == 0, "sigmoid_bwd: workspace must be 8-byte aligned");
+  int64_t nb = ceil_div64(n, 256 * 8);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), drecon, recon, dlogit,
+                     (double*)ws, n);
+  DVAE_LAUNCH_CHECK("sigmoid_bwd");
+  if (dbias) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, (int)nb, dbias);
+    DVAE_LAUNCH_CHECK("sigmoid_bwd_sum");
+  }
+  return 0;
+}

@@ -1,0 +1,90 @@
+"""ctypes binding of libdvae_hip.so (the C ABI declared in include/dvae_hip.h).
+
+There is no fallback: if the library has not been built, importing this module raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libdvae_hip.so')
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the HIP kernels first "
+        f"(`make -C {os.path.join(os.path.dirname(_HERE), 'csrc')}` or __graft_entry__.build()). "
+        "There is no CPU fallback for this package.")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+P = c_void_p
+I = c_int
+L = c_int64
+F = c_float
+
+# name -> (restype, argtypes); mirrors include/dvae_hip.h one to one
+SIGNATURES = {
+    'dvae_version': (I, []),
+    'dvae_last_error': (c_char_p, []),
+    'dvae_split_mean_diff_f32': (I, [P, P, P, L, L, L, P]),
+    'dvae_recon_loss_ws_floats': (L, [L, L, L]),
+    'dvae_recon_loss_fwd_f32': (I, [P, P, P, P, L, L, L, I, I, P]),
+    'dvae_recon_loss_bwd_f32': (I, [P, P, P, P, L, L, L, I, F, P]),
+    'dvae_reparam_fwd_f32': (I, [P, P, P, P, L, P]),
+    'dvae_reparam_bwd_f32': (I, [P, P, P, P, P, L, P]),
+    'dvae_kl_fwd_f32': (I, [P, P, P, L, L, F, P]),
+    'dvae_kl_bwd_f32': (I, [P, P, P, F, P, P, L, L, F, P]),
+    'dvae_indep_ws_floats': (L, [L, L]),
+    'dvae_indep_fwd_f32': (I, [P, P, P, P, L, L, L, P]),
+    'dvae_indep_bwd_f32': (I, [P, P, P, P, F, P, P, L, L, L, P]),
+    'dvae_bn_finalize_f32': (I, [P, L, L, L, P, P, P, P, P, F, F, P, P, P, P, P]),
+    'dvae_bn_eval_affine_f32': (I, [P, P, P, P, F, P, P, L, P]),
+    'dvae_affine_act_f32': (I, [P, P, P, I, P, L, L, P]),
+    'dvae_colsum_ws_floats': (L, [L, L]),
+    'dvae_bn_bwd_f32': (I, [P, P, P, P, P, P, P, P, P, P, L, L, P]),
+    'dvae_bias_act_bwd_f32': (I, [P, P, I, P, P, L, L, P]),
+    'dvae_sigmoid_bwd_f32': (I, [P, P, P, P, P, L, P]),
+    'dvae_gemm_ws_floats': (L, [L, L, L]),
+    'dvae_gemm_nt_f32': (I, [P, L, P, L, P, I, P, L, L, L, L, P, P]),
+    'dvae_gemm_nn_f32': (I, [P, L, P, L, P, L, L, L, L, I, P, P]),
+    'dvae_gemm_tn_f32': (I, [P, L, P, L, P, L, L, L, L, I, P, P]),
+    'dvae_pack_conv_w_f32': (I, [P, P, L, L, P]),
+    'dvae_pack_deconv_w_f32': (I, [P, P, L, L, P]),
+    'dvae_conv_stat_parts': (L, [L]),
+    'dvae_conv_stat_parts_written': (L, [L, I]),
+    'dvae_conv4s2_fwd_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P]),
+    'dvae_deconv4s2_fwd_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P]),
+    'dvae_conv_wgrad_ws_floats': (L, [L, L, L, L, L]),
+    'dvae_conv4s2_wgrad_f32': (I, [P, P, P, I, P, P, P, I, P, P, L, L, L, L, L, P]),
+    'dvae_deconv4s2_final_fwd_f32': (I, [P, P, P, I, P, P, I, P, L, L, L, L, P]),
+    'dvae_lstm_step_fwd_f32': (I, [P, L, P, L, P, L, P, L, P, L, P, P, P, P, P, L, P, L, L, L, P]),
+    'dvae_lstm_step_bwd_pointwise_f32': (I, [P, L, P, L, P, P, L, P, L, P, P, L, L, L, P]),
+    'dvae_skinny_gemm_nn_f32': (I, [P, L, P, P, P, L, L, L, L, I, P]),
+    'dvae_grad_norm_ws_floats': (L, [L, POINTER(c_int64)]),
+    'dvae_grad_norm_f32': (I, [L, POINTER(c_void_p), POINTER(c_int64), F, P, P, P]),
+    'dvae_scale_tensors_f32': (I, [L, POINTER(c_void_p), POINTER(c_int64), P, P]),
+    'dvae_adam_step_f32': (I, [L, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                               POINTER(c_int64), F, F, F, F, F, F, F, P, P]),
+}
+
+MISSING = []
+for _name, (_res, _args) in SIGNATURES.items():
+    try:
+        _fn = getattr(lib, _name)
+    except AttributeError:
+        MISSING.append(_name)
+        continue
+    _fn.restype = _res
+    _fn.argtypes = _args
+if MISSING:
+    raise ImportError(f"{LIB_PATH} does not export: {', '.join(MISSING)} (stale build?)")
+
+
+class DvaeError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        msg = lib.dvae_last_error()
+        raise DvaeError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,412 @@
+"""Tensor-level wrappers over the C ABI (include/dvae_hip.h).
+
+Every function takes CUDA(=HIP) fp32 tensors, checks what the kernels assume, and enqueues on
+torch's current stream.  PyTorch is used for device memory and streams only; there is no
+alternative code path: a CPU tensor is an error.
+"""
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from ._lib import check, lib
+
+ACT_NONE, ACT_LRELU, ACT_SIGMOID = 0, 1, 2
+Tensor = torch.Tensor
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts: Optional[Tensor]):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("hipvae ops need tensors on the GPU (no CPU path exists)")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"hipvae ops are fp32; got {t.dtype}")
+        if not t.is_contiguous():
+            raise RuntimeError("hipvae ops need contiguous tensors")
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+_WS = {}
+
+
+def workspace(nfloats: int, device, slot: str = 'main') -> Tensor:
+    """Grow-only scratch buffer per (device, slot); contents are only valid within one op."""
+    key = (torch.device(device).index, slot)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1024), dtype=torch.float32, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# ---------------------------------------------------------------------------- split
+def split_mean_diff(video: Tensor) -> Tuple[Tensor, Tensor]:
+    """video [B,T,C,H,W] -> (mean over T [B,C,H,W], frame differences [B,T-1,C,H,W])."""
+    _chk(video)
+    B, T = video.shape[:2]
+    P = video[0, 0].numel()
+    mean = torch.empty((B,) + tuple(video.shape[2:]), dtype=torch.float32, device=video.device)
+    diff = torch.empty((B, max(T - 1, 0)) + tuple(video.shape[2:]), dtype=torch.float32, device=video.device)
+    check(lib.dvae_split_mean_diff_f32(_p(video), _p(mean), _p(diff), B, T, P, _stream()), 'split_mean_diff')
+    return mean, diff
+
+
+# ---------------------------------------------------------------------------- losses
+def recon_loss_fwd(recon: Tensor, target: Tensor, kind: int, with_temporal: bool, out: Tensor):
+    _chk(recon, target, out)
+    B, T = recon.shape[:2]
+    P = recon[0, 0].numel()
+    ws = workspace(lib.dvae_recon_loss_ws_floats(B, T, P), recon.device)
+    check(lib.dvae_recon_loss_fwd_f32(_p(recon), _p(target), _p(out), _p(ws), B, T, P, kind,
+                                      int(with_temporal), _stream()), 'recon_loss_fwd')
+
+
+def recon_loss_bwd(recon: Tensor, target: Tensor, gscale: Optional[Tensor], kind: int,
+                   temporal_weight: float) -> Tensor:
+    _chk(recon, target, gscale)
+    B, T = recon.shape[:2]
+    P = recon[0, 0].numel()
+    d = torch.empty_like(recon)
+    check(lib.dvae_recon_loss_bwd_f32(_p(recon), _p(target), _p(gscale), _p(d), B, T, P, kind,
+                                      float(temporal_weight), _stream()), 'recon_loss_bwd')
+    return d
+
+
+def reparam_fwd(mu, logvar, eps):
+    _chk(mu, logvar, eps)
+    z = torch.empty_like(mu)
+    check(lib.dvae_reparam_fwd_f32(_p(mu), _p(logvar), _p(eps), _p(z), mu.numel(), _stream()), 'reparam_fwd')
+    return z
+
+
+def reparam_bwd(dz, logvar, eps):
+    _chk(dz, logvar, eps)
+    dmu = torch.empty_like(dz)
+    dlv = torch.empty_like(dz)
+    check(lib.dvae_reparam_bwd_f32(_p(dz), _p(logvar), _p(eps), _p(dmu), _p(dlv), dz.numel(), _stream()),
+          'reparam_bwd')
+    return dmu, dlv
+
+
+def kl_fwd(mu, logvar, free_bits: float, out: Tensor):
+    _chk(mu, logvar, out)
+    B, D = mu.shape
+    check(lib.dvae_kl_fwd_f32(_p(mu), _p(logvar), _p(out), B, D, float(free_bits), _stream()), 'kl_fwd')
+
+
+def kl_bwd(mu, logvar, gscale, coef: float, free_bits: float):
+    _chk(mu, logvar, gscale)
+    B, D = mu.shape
+    dmu = torch.empty_like(mu)
+    dlv = torch.empty_like(mu)
+    check(lib.dvae_kl_bwd_f32(_p(mu), _p(logvar), _p(gscale), float(coef), _p(dmu), _p(dlv), B, D,
+                              float(free_bits), _stream()), 'kl_bwd')
+    return dmu, dlv
+
+
+def indep_fwd(zc, zm, out: Tensor) -> Tensor:
+    """Returns the saved workspace (correlation + statistics) needed by indep_bwd."""
+    _chk(zc, zm, out)
+    B, Dc = zc.shape
+    Dm = zm.shape[1]
+    ws = torch.empty(lib.dvae_indep_ws_floats(Dc, Dm), dtype=torch.float32, device=zc.device)
+    check(lib.dvae_indep_fwd_f32(_p(zc), _p(zm), _p(out), _p(ws), B, Dc, Dm, _stream()), 'indep_fwd')
+    return ws
+
+
+def indep_bwd(zc, zm, ws, gscale, coef: float):
+    _chk(zc, zm, ws, gscale)
+    B, Dc = zc.shape
+    Dm = zm.shape[1]
+    dzc = torch.empty_like(zc)
+    dzm = torch.empty_like(zm)
+    check(lib.dvae_indep_bwd_f32(_p(zc), _p(zm), _p(ws), _p(gscale), float(coef), _p(dzc), _p(dzm), B, Dc, Dm,
+                                 _stream()), 'indep_bwd')
+    return dzc, dzm
+
+
+# ---------------------------------------------------------------------------- BatchNorm glue
+def bn_finalize(partials: Tensor, nparts: int, M: int, gamma, beta, running_mean, running_var, nbt,
+                momentum: float, eps: float):
+    """-> (scale, shift, mean, invstd); updates the running buffers in place when given."""
+    _chk(partials, gamma, beta, running_mean, running_var)
+    C = gamma.numel()
+    out = torch.empty(4, C, dtype=torch.float32, device=gamma.device)
+    check(lib.dvae_bn_finalize_f32(_p(partials), nparts, M, C, _p(gamma), _p(beta), _p(running_mean),
+                                   _p(running_var), None if nbt is None else nbt.data_ptr(), float(momentum),
+                                   float(eps), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _stream()),
+          'bn_finalize')
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps: float):
+    _chk(gamma, beta, running_mean, running_var)
+    C = gamma.numel()
+    out = torch.empty(2, C, dtype=torch.float32, device=gamma.device)
+    check(lib.dvae_bn_eval_affine_f32(_p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps),
+                                      _p(out[0]), _p(out[1]), C, _stream()), 'bn_eval_affine')
+    return out[0], out[1]
+
+
+def affine_act(x: Tensor, scale, shift, act: int) -> Tensor:
+    _chk(x, scale, shift)
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    check(lib.dvae_affine_act_f32(_p(x), _p(scale), _p(shift), act, _p(out), x.numel() // C, C, _stream()),
+          'affine_act')
+    return out
+
+
+def bn_bwd(du: Tensor, y: Tensor, scale, shift, mean, invstd, gamma):
+    """Overwrites du with dL/dy; returns (dgamma, dbeta)."""
+    _chk(du, y, scale, shift, mean, invstd, gamma)
+    C = y.shape[-1]
+    M = y.numel() // C
+    dgb = torch.empty(2, C, dtype=torch.float32, device=y.device)
+    ws = workspace(2 * lib.dvae_colsum_ws_floats(M, C), y.device)
+    check(lib.dvae_bn_bwd_f32(_p(du), _p(y), _p(scale), _p(shift), _p(mean), _p(invstd), _p(gamma), _p(dgb[0]),
+                              _p(dgb[1]), _p(ws), M, C, _stream()), 'bn_bwd')
+    return dgb[0], dgb[1]
+
+
+def bias_act_bwd(dout: Tensor, out: Optional[Tensor], act: int, want_bias: bool) -> Optional[Tensor]:
+    """dout <- dout * act'(out) in place; returns column sums (bias gradient) if wanted."""
+    _chk(dout, out)
+    N = dout.shape[-1]
+    M = dout.numel() // N
+    db = torch.empty(N, dtype=torch.float32, device=dout.device) if want_bias else None
+    ws = workspace(lib.dvae_colsum_ws_floats(M, N), dout.device)
+    check(lib.dvae_bias_act_bwd_f32(_p(dout), _p(out), act, _p(db), _p(ws), M, N, _stream()), 'bias_act_bwd')
+    return db
+
+
+def sigmoid_bwd(drecon: Tensor, recon: Tensor, want_bias: bool = True):
+    _chk(drecon, recon)
+    dl = torch.empty_like(drecon)
+    db = torch.empty(1, dtype=torch.float32, device=recon.device) if want_bias else None
+    ws = workspace(4096, recon.device)
+    check(lib.dvae_sigmoid_bwd_f32(_p(drecon), _p(recon), _p(dl), _p(db), _p(ws), recon.numel(), _stream()),
+          'sigmoid_bwd')
+    return dl, db
+
+
+# ---------------------------------------------------------------------------- GEMMs
+def _rows(t: Tensor) -> Tuple[int, int]:
+    """(rows, row stride) of a 2-D tensor whose last dim is contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError("expected a 2-D tensor with a contiguous last dimension")
+    return t.shape[0], t.stride(0)
+
+
+def _chk2(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise RuntimeError("hipvae GEMMs need fp32 GPU tensors (no CPU path exists)")
+
+
+def gemm_nt(a: Tensor, b: Tensor, bias: Optional[Tensor] = None, act: int = ACT_NONE,
+            out: Optional[Tensor] = None) -> Tensor:
+    """act(a[M,K] @ b[N,K]^T + bias)."""
+    _chk2(a, b, bias, out)
+    M, lda = _rows(a)
+    N, ldb = _rows(b)
+    K = a.shape[1]
+    assert b.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    ldc = out.stride(0)
+    ws = workspace(lib.dvae_gemm_ws_floats(M, N, K), a.device)
+    check(lib.dvae_gemm_nt_f32(_p(a), lda, _p(b), ldb, _p(bias), act, _p(out), ldc, M, N, K, _p(ws), _stream()),
+          'gemm_nt')
+    return out
+
+
+def gemm_nn(a: Tensor, b: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """a[M,K] @ b[K,N]."""
+    _chk2(a, b, out)
+    M, lda = _rows(a)
+    K, ldb = _rows(b)
+    N = b.shape[1]
+    assert a.shape[1] == K
+    if out is None:
+        assert not accumulate
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    ws = workspace(lib.dvae_gemm_ws_floats(M, N, K), a.device)
+    check(lib.dvae_gemm_nn_f32(_p(a), lda, _p(b), ldb, _p(out), out.stride(0), M, N, K, int(accumulate), _p(ws),
+                               _stream()), 'gemm_nn')
+    return out
+
+
+def gemm_tn(a: Tensor, b: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """a[K,M]^T @ b[K,N]."""
+    _chk2(a, b, out)
+    K, lda = _rows(a)
+    K2, ldb = _rows(b)
+    assert K == K2
+    M, N = a.shape[1], b.shape[1]
+    if out is None:
+        assert not accumulate
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    ws = workspace(lib.dvae_gemm_ws_floats(M, N, K), a.device)
+    check(lib.dvae_gemm_tn_f32(_p(a), lda, _p(b), ldb, _p(out), out.stride(0), M, N, K, int(accumulate), _p(ws),
+                               _stream()), 'gemm_tn')
+    return out
+
+
+# ---------------------------------------------------------------------------- conv family
+def pack_conv_w(w: Tensor) -> Tensor:
+    """[A][Bc][4][4] -> [A][4][4][Bc]"""
+    _chk(w)
+    A, Bc = w.shape[:2]
+    wp = torch.empty(A, 4, 4, Bc, dtype=torch.float32, device=w.device)
+    check(lib.dvae_pack_conv_w_f32(_p(w), _p(wp), A, Bc, _stream()), 'pack_conv_w')
+    return wp
+
+
+def pack_deconv_w(w: Tensor) -> Tensor:
+    """[Kc][Nc][4][4] -> [4 phases][Nc][2][2][Kc]"""
+    _chk(w)
+    Kc, Nc = w.shape[:2]
+    wp = torch.empty(4, Nc, 2, 2, Kc, dtype=torch.float32, device=w.device)
+    check(lib.dvae_pack_deconv_w_f32(_p(w), _p(wp), Kc, Nc, _stream()), 'pack_deconv_w')
+    return wp
+
+
+def conv4s2_fwd(x: Tensor, scale, shift, act: int, wp: Tensor, want_stats: bool):
+    """x [N,H,W,Cin] -> (y [N,H/2,W/2,Cout], stat partials or None, number of partial rows)."""
+    _chk(x, scale, shift, wp)
+    N, H, W, Cin = x.shape
+    Cout = wp.shape[0]
+    y = torch.empty(N, H // 2, W // 2, Cout, dtype=torch.float32, device=x.device)
+    nparts = lib.dvae_conv_stat_parts_written(N * (H // 2) * (W // 2), 1)
+    stats = torch.empty(nparts, 2, Cout, dtype=torch.float32, device=x.device) if want_stats else None
+    check(lib.dvae_conv4s2_fwd_f32(_p(x), _p(scale), _p(shift), act, _p(wp), _p(y), _p(stats), N, H, W, Cin, Cout,
+                                   _stream()), 'conv4s2_fwd')
+    return y, stats, nparts
+
+
+def deconv4s2_fwd(x: Tensor, scale, shift, act: int, wp: Tensor, want_stats: bool):
+    """x [N,H,W,Cin] -> (y [N,2H,2W,Cout], stat partials or None, number of partial rows)."""
+    _chk(x, scale, shift, wp)
+    N, H, W, Cin = x.shape
+    Cout = wp.shape[1]
+    y = torch.empty(N, 2 * H, 2 * W, Cout, dtype=torch.float32, device=x.device)
+    nparts = lib.dvae_conv_stat_parts_written(N * H * W, 4)
+    stats = torch.empty(nparts, 2, Cout, dtype=torch.float32, device=x.device) if want_stats else None
+    check(lib.dvae_deconv4s2_fwd_f32(_p(x), _p(scale), _p(shift), act, _p(wp), _p(y), _p(stats), N, H, W, Cin,
+                                     Cout, _stream()), 'deconv4s2_fwd')
+    return y, stats, nparts
+
+
+def conv4s2_wgrad(P: Tensor, p_scale, p_shift, p_act: int, Q: Tensor, q_scale, q_shift, q_act: int) -> Tensor:
+    """P [N,Hs,Ws,C1], Q [N,2Hs,2Ws,C2] -> dw [C1][C2][4][4]."""
+    _chk(P, p_scale, p_shift, Q, q_scale, q_shift)
+    N, Hs, Ws, C1 = P.shape
+    C2 = Q.shape[3]
+    assert Q.shape[1] == 2 * Hs and Q.shape[2] == 2 * Ws and Q.shape[0] == N
+    dw = torch.empty(C1, C2, 4, 4, dtype=torch.float32, device=P.device)
+    ws = workspace(lib.dvae_conv_wgrad_ws_floats(N, Hs, Ws, C1, C2), P.device)
+    check(lib.dvae_conv4s2_wgrad_f32(_p(P), _p(p_scale), _p(p_shift), p_act, _p(Q), _p(q_scale), _p(q_shift),
+                                     q_act, _p(dw), _p(ws), N, Hs, Ws, C1, C2, _stream()), 'conv4s2_wgrad')
+    return dw
+
+
+def deconv4s2_final_fwd(x: Tensor, scale, shift, act: int, w: Tensor, bias: Optional[Tensor],
+                        out_act: int) -> Tensor:
+    """x [N,H,W,Cin], w [Cin][1][4][4] -> y [N,2H,2W]."""
+    _chk(x, scale, shift, w, bias)
+    N, H, W, Cin = x.shape
+    y = torch.empty(N, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
+    check(lib.dvae_deconv4s2_final_fwd_f32(_p(x), _p(scale), _p(shift), act, _p(w), _p(bias), out_act, _p(y), N, H,
+                                           W, Cin, _stream()), 'deconv4s2_final_fwd')
+    return y
+
+
+# ---------------------------------------------------------------------------- LSTM steps
+def lstm_step_fwd(xproj, x, w_ih, h_prev, c_prev, w_hh, b_ih, b_hh, gates_out, h_out, c_out):
+    """All row tensors are 2-D views with contiguous last dim (row strides are passed through)."""
+    _chk2(xproj, x, w_ih, h_prev, c_prev, w_hh, b_ih, b_hh, gates_out, h_out, c_out)
+    B, H = h_out.shape
+    I = 0 if x is None else x.shape[1]
+    ld = lambda t: 0 if t is None else t.stride(0)
+    check(lib.dvae_lstm_step_fwd_f32(_p(xproj), ld(xproj), _p(x), ld(x), _p(w_ih), I, _p(h_prev), ld(h_prev),
+                                     _p(c_prev), ld(c_prev), _p(w_hh), _p(b_ih), _p(b_hh), _p(gates_out),
+                                     _p(h_out), ld(h_out), _p(c_out), ld(c_out), B, H, _stream()),
+          'lstm_step_fwd')
+
+
+def lstm_step_bwd_pointwise(dh, dc, gates, c_prev, c, dgates, dc_prev):
+    _chk2(dh, dc, gates, c_prev, c, dgates, dc_prev)
+    B, H = c.shape
+    ld = lambda t: 0 if t is None else t.stride(0)
+    check(lib.dvae_lstm_step_bwd_pointwise_f32(_p(dh), ld(dh), _p(dc), ld(dc), _p(gates), _p(c_prev), ld(c_prev),
+                                               _p(c), ld(c), _p(dgates), _p(dc_prev), ld(dc_prev), B, H, _stream()),
+          'lstm_step_bwd_pointwise')
+
+
+def skinny_gemm_nn(dg: Tensor, w: Tensor, w2: Optional[Tensor], out: Tensor, accumulate: bool):
+    """out[B,N] (+)= dg[B,K] @ w[K,N] (+ dg @ w2)."""
+    _chk2(dg, w, w2, out)
+    B, K = dg.shape
+    N = w.shape[1]
+    assert w.shape[0] == K and w.is_contiguous() and (w2 is None or (w2.shape == w.shape and w2.is_contiguous()))
+    check(lib.dvae_skinny_gemm_nn_f32(_p(dg), dg.stride(0), _p(w), _p(w2), _p(out), out.stride(0), B, N, K,
+                                      int(accumulate), _stream()), 'skinny_gemm_nn')
+
+
+# ---------------------------------------------------------------------------- optimiser
+class TensorTable:
+    """Host-side pointer/size arrays for the multi-tensor kernels, rebuilt only when pointers move."""
+
+    def __init__(self):
+        self.key = None
+        self.arrays = None
+
+    def get(self, lists: Sequence[Sequence[Tensor]]):
+        key = tuple(t.data_ptr() for ts in lists for t in ts)
+        if key != self.key:
+            n = len(lists[0])
+            arrs = []
+            for ts in lists:
+                for t in ts:
+                    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                        raise RuntimeError("multi-tensor ops need contiguous fp32 GPU tensors")
+                arrs.append((ctypes.c_void_p * n)(*[t.data_ptr() for t in ts]))
+            numel = (ctypes.c_int64 * n)(*[t.numel() for t in lists[0]])
+            self.key = key
+            self.arrays = (n, arrs, numel)
+        return self.arrays
+
+
+def grad_norm(grads: List[Tensor], max_norm: float, out: Tensor, table: Optional[TensorTable] = None):
+    """out[0] = total 2-norm, out[1] = clip coefficient."""
+    table = table or TensorTable()
+    n, (g,), numel = table.get([grads])
+    ws = workspace(lib.dvae_grad_norm_ws_floats(n, numel), grads[0].device, 'norm')
+    check(lib.dvae_grad_norm_f32(n, g, numel, float(max_norm), _p(out), _p(ws), _stream()), 'grad_norm')
+
+
+def scale_tensors(tensors: List[Tensor], coef: Tensor, table: Optional[TensorTable] = None):
+    table = table or TensorTable()
+    n, (g,), numel = table.get([tensors])
+    check(lib.dvae_scale_tensors_f32(n, g, numel, _p(coef), _stream()), 'scale_tensors')
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+              grad_coef: Optional[Tensor], table: Optional[TensorTable] = None):
+    table = table or TensorTable()
+    n, (p, g, m, v), numel = table.get([params, grads, exp_avg, exp_avg_sq])
+    check(lib.dvae_adam_step_f32(n, p, g, m, v, numel, float(lr), float(beta1), float(beta2), float(eps),
+                                 float(weight_decay), float(bc1), float(bc2), _p(grad_coef), _stream()),
+          'adam_step')

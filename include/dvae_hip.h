@@ -1,0 +1,210 @@
+/*
+ * C ABI of libdvae_hip.so: the gfx950 (MI355X) kernels behind the video-VAE training and inference
+ * hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 data unless said otherwise; the library borrows it for
+ *    the duration of the call, enqueues work on `stream` and returns without synchronising;
+ *  - nothing here allocates, frees or synchronises: scratch is passed in (`ws` arguments) and its
+ *    size in floats is given by the matching *_ws_floats() helper;
+ *  - return value 0 on success, -EINVAL for a shape/argument the kernels do not support (nothing
+ *    launched), -EIO if a launch failed; dvae_last_error() returns the message of the last failure
+ *    on the calling thread;
+ *  - activations are NHWC with frames folded into the leading dimension (rows = frame*H*W, channels
+ *    contiguous); conv weights arrive in packed layouts produced by the dvae_pack_* calls.
+ *
+ * The reference has no native interface: its boundary is the Python surface cited per entry point
+ * (paths relative to the reference tree).
+ */
+#ifndef DVAE_HIP_H
+#define DVAE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dvae_stream_t; /* hipStream_t */
+
+#define DVAE_ACT_NONE 0
+#define DVAE_ACT_LRELU 1   /* LeakyReLU(0.2) */
+#define DVAE_ACT_SIGMOID 2
+
+int dvae_version(void);
+const char* dvae_last_error(void);
+
+/* ---- content / motion split: video.mean(dim=1) (models/encoders.py:251) and
+ *      video[:,1:]-video[:,:-1] (models/encoders.py:302-303) in one pass.
+ *      video [B,T,P], mean [B,P], diff [B,T-1,P]; P % 4 == 0. */
+int dvae_split_mean_diff_f32(const float* video, float* mean, float* diff, int64_t B, int64_t T,
+                             int64_t P, dvae_stream_t stream);
+
+/* ---- reconstruction loss (models/disentangled_vae.py:246-253,263-268; models/lstm_vae.py:182-189;
+ *      models/baseline_vae.py:222-229).  kind 0 = MSE, 1 = BCE with log terms clamped at -100.
+ *      out[0] = mean loss per pixel, out[1] = out[0]*T*P, out[2] = temporal-difference MSE * (T-1)*P
+ *      (0 when with_temporal == 0).  ws: dvae_recon_loss_ws_floats(B,T,P) floats. */
+int64_t dvae_recon_loss_ws_floats(int64_t B, int64_t T, int64_t P);
+int dvae_recon_loss_fwd_f32(const float* recon, const float* target, float* out, float* ws, int64_t B,
+                            int64_t T, int64_t P, int kind, int with_temporal, dvae_stream_t stream);
+/* d(out[1] + temporal_weight*out[2]) / d recon, times the device scalar *gscale. */
+int dvae_recon_loss_bwd_f32(const float* recon, const float* target, const float* gscale, float* drecon,
+                            int64_t B, int64_t T, int64_t P, int kind, float temporal_weight,
+                            dvae_stream_t stream);
+
+/* ---- reparameterisation (models/encoders.py:207-214): z = mu + eps*exp(0.5*logvar), n elements. */
+int dvae_reparam_fwd_f32(const float* mu, const float* logvar, const float* eps, float* z, int64_t n,
+                         dvae_stream_t stream);
+int dvae_reparam_bwd_f32(const float* dz, const float* logvar, const float* eps, float* dmu,
+                         float* dlogvar, int64_t n, dvae_stream_t stream);
+
+/* ---- KL term (models/disentangled_vae.py:255-259; free-bits floor of models/lstm_vae.py:191-200).
+ *      mu, logvar [B,D].  out[0] = mean_b sum_d max(kl_bd, free_bits) (no floor when free_bits <= 0),
+ *      out[1] = the same without the floor, out[2] = mean over all B*D of the floored values. */
+int dvae_kl_fwd_f32(const float* mu, const float* logvar, float* out, int64_t B, int64_t D,
+                    float free_bits, dvae_stream_t stream);
+/* dmu, dlogvar of coef * (*gscale) * out[0]. */
+int dvae_kl_bwd_f32(const float* mu, const float* logvar, const float* gscale, float coef, float* dmu,
+                    float* dlogvar, int64_t B, int64_t D, float free_bits, dvae_stream_t stream);
+
+/* ---- independence term (models/disentangled_vae.py:270-278): mean of the squared cross-correlation
+ *      of the standardised latents (unbiased std + 1e-8, correlation / B).
+ *      zc [B,Dc], zm [B,Dm]; out[0] = loss.  ws: Dc*Dm + 2*Dc + 2*Dm + Dc floats, reused by bwd. */
+int64_t dvae_indep_ws_floats(int64_t Dc, int64_t Dm);
+int dvae_indep_fwd_f32(const float* zc, const float* zm, float* out, float* ws, int64_t B, int64_t Dc,
+                       int64_t Dm, dvae_stream_t stream);
+int dvae_indep_bwd_f32(const float* zc, const float* zm, const float* ws, const float* gscale, float coef,
+                       float* dzc, float* dzm, int64_t B, int64_t Dc, int64_t Dm, dvae_stream_t stream);
+
+/* ---- BatchNorm2d pieces (models/encoders.py:35,79; models/decoders.py:44), channels-last [M,C].
+ *      Forward statistics come out of the conv kernels as per-workgroup partial sums
+ *      partials[nparts][2][C] (sum, sum of squares).  Finalize turns them into the folded affine
+ *      scale = gamma*invstd, shift = beta - mean*scale that the NEXT kernel applies on load, keeps
+ *      mean/invstd for backward and updates the running buffers (momentum 0.1, unbiased variance,
+ *      num_batches_tracked += 1; pass NULL to skip). */
+int dvae_bn_finalize_f32(const float* partials, int64_t nparts, int64_t M, int64_t C, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var,
+                         int64_t* num_batches_tracked, float momentum, float eps, float* scale,
+                         float* shift, float* mean, float* invstd, dvae_stream_t stream);
+/* Eval mode: scale/shift from the running statistics. */
+int dvae_bn_eval_affine_f32(const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float eps, float* scale, float* shift, int64_t C,
+                            dvae_stream_t stream);
+/* out = act(x*scale[c]+shift[c]) materialised, [M,C]. */
+int dvae_affine_act_f32(const float* x, const float* scale, const float* shift, int act, float* out,
+                        int64_t M, int64_t C, dvae_stream_t stream);
+/* Backward of BN + LeakyReLU given du = dL/d(post-activation), y = raw conv output.
+ * Step 1 accumulates sum(dz) and sum(dz*xhat) per channel (dz = du*lrelu'(y*scale+shift)) and turns
+ * them into dgamma, dbeta; step 2 overwrites du with dL/dy.  ws: dvae_colsum_ws_floats(M,C)*2. */
+int64_t dvae_colsum_ws_floats(int64_t M, int64_t C);
+int dvae_bn_bwd_f32(float* du, const float* y, const float* scale, const float* shift, const float* mean,
+                    const float* invstd, const float* gamma, float* dgamma, float* dbeta, float* ws,
+                    int64_t M, int64_t C, dvae_stream_t stream);
+/* Backward of (bias +) activation of a Linear layer: dpre = dout * act'(out) written in place over
+ * dout (act NONE leaves it untouched), dbias[n] = sum_m dpre[m][n] (NULL to skip). [M,N], N%4==0. */
+int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, float* dbias, float* ws, int64_t M,
+                          int64_t N, dvae_stream_t stream);
+/* dlogit = drecon * r * (1-r) (sigmoid backward), dbias[0] = sum(dlogit); n elements. */
+int dvae_sigmoid_bwd_f32(const float* drecon, const float* recon, float* dlogit, float* dbias, float* ws,
+                         int64_t n, dvae_stream_t stream);
+
+/* ---- Linear layers (nn.Linear at models/encoders.py:43-46,87-90,197-198; models/decoders.py:30-33,
+ *      91-92,102-105,218-219,228-231) as f32-MFMA GEMMs, row-major, K%4==0 / N%4==0 as noted.
+ *      ws: dvae_gemm_ws_floats(M,N,K) floats (split-K slabs). */
+int64_t dvae_gemm_ws_floats(int64_t M, int64_t N, int64_t K);
+/* C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]); lda/ldb/ldc row strides in floats; K%4==0. */
+int dvae_gemm_nt_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, int act,
+                     float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float* ws,
+                     dvae_stream_t stream);
+/* C[M,N] (+)= A[M,K] * B[K,N]; K%4==0, N%4==0; accumulate != 0 adds into C. */
+int dvae_gemm_nn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                     int64_t M, int64_t N, int64_t K, int accumulate, float* ws, dvae_stream_t stream);
+/* C[M,N] (+)= A[K,M]^T * B[K,N]; M%4==0, N%4==0 (weight gradients: K is the batch dimension). */
+int dvae_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                     int64_t M, int64_t N, int64_t K, int accumulate, float* ws, dvae_stream_t stream);
+
+/* ---- 4x4 stride-2 pad-1 convolution family (nn.Conv2d at models/encoders.py:32,76 and
+ *      nn.ConvTranspose2d at models/decoders.py:40,49) as implicit GEMMs on f32 MFMA.
+ *      x [N,H,W,Cin] NHWC; in_scale/in_shift/in_act: affine + activation applied to x as it is
+ *      loaded (the previous layer's folded BatchNorm; NULL scale = identity);  zero padding is applied
+ *      AFTER that transform.  stat_partials (NULL to skip) receives per-workgroup column sums and
+ *      sums of squares of the raw output, dvae_conv_stat_parts(...) rows of [2][Cout]. */
+/* weight packs: torch Conv2d weight [A][Bc][4][4] -> [A][kh][kw][Bc]  */
+int dvae_pack_conv_w_f32(const float* w, float* wp, int64_t A, int64_t Bc, dvae_stream_t stream);
+/* torch weight [Kc][Nc][4][4] -> [phase=ph*2+pw][Nc][th][tw][Kc], the four 2x2 sub-pixel filters of
+ * the transposed convolution (kh = 1,3 for even output rows, 0,2 for odd ones). */
+int dvae_pack_deconv_w_f32(const float* w, float* wp, int64_t Kc, int64_t Nc, dvae_stream_t stream);
+int64_t dvae_conv_stat_parts(int64_t M_rows);
+/* exact number of partial rows a forward launch with that many GEMM rows per phase writes
+ * (phases = 1 for the convolution, 4 for the transposed convolution) */
+int64_t dvae_conv_stat_parts_written(int64_t M_rows_per_phase, int phases);
+/* y[N,H/2,W/2,Cout] = conv(act(x)) with wp = packed [Cout][4][4][Cin]; Cin == 1 or Cin%4 == 0. */
+int dvae_conv4s2_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
+                         const float* wp, float* y, float* stat_partials, int64_t N, int64_t H, int64_t W,
+                         int64_t Cin, int64_t Cout, dvae_stream_t stream);
+/* y[N,2H,2W,Cout] = conv_transpose(act(x)) with wp = dvae_pack_deconv_w_f32 output
+ * (Kc = Cin, Nc = Cout); Cin%4 == 0.  Also the data gradient of dvae_conv4s2_fwd_f32. */
+int dvae_deconv4s2_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
+                           const float* wp, float* y, float* stat_partials, int64_t N, int64_t H,
+                           int64_t W, int64_t Cin, int64_t Cout, dvae_stream_t stream);
+/* Weight gradient shared by both layer kinds:
+ *   dw[c1][c2][kh][kw] = sum_{n,a,b} P[n,a,b,c1] * Q[n,2a-1+kh,2b-1+kw,c2]
+ * P [N,Hs,Ws,C1] is the small-resolution tensor, Q [N,2Hs,2Ws,C2] the large one (Conv2d: P = dY,
+ * Q = layer input; ConvTranspose2d: P = layer input, Q = dY), each with its own load-time transform.
+ * dw is in the torch layout [C1][C2][4][4].  C1%4==0; C2 == 1 or C2%4 == 0.
+ * ws: dvae_conv_wgrad_ws_floats(N,Hs,Ws,C1,C2). */
+int64_t dvae_conv_wgrad_ws_floats(int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2);
+int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, const float* p_shift, int p_act,
+                           const float* Q, const float* q_scale, const float* q_shift, int q_act,
+                           float* dw, float* ws, int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2,
+                           dvae_stream_t stream);
+/* Final decoder layer (models/decoders.py:49-53,67-68): ConvTranspose2d(Cin -> 1, bias) + sigmoid.
+ * x [N,H,W,Cin] (+ load-time transform), w torch layout [Cin][1][4][4], y [N,2H,2W]. Cin%4==0. */
+int dvae_deconv4s2_final_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
+                                 const float* w, const float* bias, int out_act, float* y, int64_t N,
+                                 int64_t H, int64_t W, int64_t Cin, dvae_stream_t stream);
+
+/* ---- LSTM (nn.LSTM at models/encoders.py:145-152, models/decoders.py:94-100,221-226), gate order
+ *      i,f,g,o.  One call advances one layer/direction set by one time step for all B rows:
+ *        pre = [xproj] + [x * w_ih^T] + h_prev * w_hh^T + [b_ih + b_hh]
+ *      gates_out [B,4H] receives the activated gates (kept for backward), h_out/c_out the new state.
+ *      Every row-pointer has its own row stride (floats) so batch-first sequences can be addressed in
+ *      place.  H%8==0, I%4==0. */
+int dvae_lstm_step_fwd_f32(const float* xproj, int64_t ld_xproj, const float* x, int64_t ld_x,
+                           const float* w_ih, int64_t I, const float* h_prev, int64_t ld_h,
+                           const float* c_prev, int64_t ld_c, const float* w_hh, const float* b_ih,
+                           const float* b_hh, float* gates_out, float* h_out, int64_t ld_hout,
+                           float* c_out, int64_t ld_cout, int64_t B, int64_t H, dvae_stream_t stream);
+/* Pointwise part of one backward step: from dh (total gradient reaching h_t), dc (carried), the saved
+ * activated gates, c_prev and c: dgates [B,4H] (pre-activation gradients) and dc_prev. */
+int dvae_lstm_step_bwd_pointwise_f32(const float* dh, int64_t ld_dh, const float* dc, int64_t ld_dc,
+                                     const float* gates, const float* c_prev, int64_t ld_cprev,
+                                     const float* c, int64_t ld_c, float* dgates, float* dc_prev,
+                                     int64_t ld_dcprev, int64_t B, int64_t H, dvae_stream_t stream);
+/* Skinny GEMM of the recurrence: out[B,N] (+)= dg[B,K] * w[K,N] (+ dg * w2[K,N]); latency-oriented
+ * (32x32 output tiles, K split over the four waves of a workgroup).  K%4==0, N%4==0. */
+int dvae_skinny_gemm_nn_f32(const float* dg, int64_t ld_dg, const float* w, const float* w2, float* out,
+                            int64_t ld_out, int64_t B, int64_t N, int64_t K, int accumulate,
+                            dvae_stream_t stream);
+
+/* ---- optimiser (torch.optim.Adam with L2 weight decay and nn.utils.clip_grad_norm_ as called at
+ *      training/trainer.py:56-61,198-204).  Host arrays of n device pointers / sizes.
+ *      dvae_grad_norm: total 2-norm of all gradients -> norm_out[0], and
+ *      norm_out[1] = min(1, max_norm/(norm+1e-6)) (1 when max_norm <= 0).
+ *      ws: dvae_grad_norm_ws_floats(n, numel). */
+int64_t dvae_grad_norm_ws_floats(int64_t n, const int64_t* numel);
+int dvae_grad_norm_f32(int64_t n, const float* const* grads, const int64_t* numel, float max_norm,
+                       float* norm_out, float* ws, dvae_stream_t stream);
+/* Scales every gradient in place by *coef (device scalar). */
+int dvae_scale_tensors_f32(int64_t n, float* const* tensors, const int64_t* numel, const float* coef,
+                           dvae_stream_t stream);
+/* One Adam step on n tensors; gradients are multiplied by *grad_coef (device scalar, NULL = 1) as
+ * they are read.  bias_correction1 = 1-beta1^t, bias_correction2 = 1-beta2^t computed by the caller. */
+int dvae_adam_step_f32(int64_t n, float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, float bias_correction1, float bias_correction2,
+                       const float* grad_coef, dvae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

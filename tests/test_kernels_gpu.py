@@ -1,0 +1,454 @@
+"""Per-kernel parity of the HIP library (through its C ABI) against fp64 CPU restatements.
+
+Tolerances: fp32 kernels vs an fp64 reference of the same operation; relative L2 error <= 2e-5 for
+GEMM-shaped kernels (K up to a few thousand), element tolerances written per test.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vae_oracle as O
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from hipvae import ops as _ops
+    assert torch.cuda.is_available()
+    return _ops
+
+
+def dev(t):
+    return t.to('cuda', torch.float32).contiguous()
+
+
+def rel_err(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((got - ref).norm() / max(float(ref.norm()), 1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+
+
+# ------------------------------------------------------------------ split / losses
+@pytest.mark.parametrize('B,T', [(3, 6), (2, 20), (1, 1), (5, 2)])
+def test_split_mean_diff(ops, B, T):
+    v = torch.rand(B, T, 1, 64, 64, generator=torch.Generator().manual_seed(1))
+    mean, diff = ops.split_mean_diff(dev(v))
+    rm, rd = O.split_mean_diff(v)
+    assert mean.shape == rm.shape and diff.shape == rd.shape
+    torch.testing.assert_close(mean.cpu(), rm, rtol=1e-6, atol=1e-7)
+    assert torch.equal(diff.cpu(), rd)          # differences of fp32 values are exact in both
+
+
+@pytest.mark.parametrize('kind', ['mse', 'bce'])
+@pytest.mark.parametrize('tw', [0.0, 0.05])
+def test_recon_loss(ops, kind, tw):
+    B, T = 3, 5
+    g = torch.Generator().manual_seed(2)
+    target = (torch.rand(B, T, 1, 64, 64, generator=g) > 0.9).float() * torch.rand(B, T, 1, 64, 64, generator=g)
+    recon = torch.sigmoid(torch.randn(B, T, 1, 64, 64, generator=g) * 3)
+    recon[0, 0, 0, 0, :4] = torch.tensor([0.0, 1.0, 1e-30, 1 - 1e-7])   # exercises the -100 clamp
+    r64 = recon.double().requires_grad_(True)
+    t64 = target.double()
+    rl = O.recon_term(r64, t64, kind)
+    tl = O.temporal_term(r64, t64)
+    out = torch.zeros(4, device='cuda')
+    ops.recon_loss_fwd(dev(recon), dev(target), 0 if kind == 'mse' else 1, tw > 0, out)
+    o = out.cpu().double()
+    assert abs(o[0] - rl.item()) <= 1e-6 * abs(rl.item())
+    assert abs(o[1] - rl.item() * T * 4096) <= 1e-6 * abs(rl.item() * T * 4096)
+    if tw > 0:
+        assert abs(o[2] - tl.item()) <= 1e-5 * abs(tl.item())
+    else:
+        assert o[2] == 0
+    # backward, scaled by a device scalar
+    gs = torch.tensor([0.7], device='cuda')
+    d = ops.recon_loss_bwd(dev(recon), dev(target), gs, 0 if kind == 'mse' else 1, tw)
+    if kind == 'mse':
+        total = 0.7 * (rl * T * 4096 + tw * tl)
+        (gref,) = torch.autograd.grad(total, r64)
+    else:
+        # torch's BCE backward formula (r-x)/max((1-r)r,1e-12), not the derivative of the clamped log
+        gref = 0.7 * ((r64 - t64) / torch.clamp((1 - r64) * r64, min=1e-12) / B).detach()
+        if tw > 0:
+            (gt,) = torch.autograd.grad(0.7 * tw * tl, r64)
+            gref = gref + gt
+    mask = torch.ones_like(recon, dtype=torch.bool)
+    mask[0, 0, 0, 0, :4] = False
+    assert rel_err(d.cpu()[mask], gref[mask]) < 2e-6
+    assert torch.isfinite(d).all()
+
+
+def test_reparam_and_kl(ops):
+    B, D = 7, 24
+    mu, lv, eps = rnd(B, D, seed=3), rnd(B, D, seed=4) * 0.5, rnd(B, D, seed=5)
+    z = ops.reparam_fwd(dev(mu), dev(lv), dev(eps))
+    assert rel_err(z, O.reparameterize(mu, lv, eps)) < 1e-6
+    dz = rnd(B, D, seed=6)
+    dmu, dlv = ops.reparam_bwd(dev(dz), dev(lv), dev(eps))
+    assert rel_err(dmu, dz) == 0
+    assert rel_err(dlv, dz * eps * 0.5 * torch.exp(0.5 * lv)) < 1e-6
+    for fb in (0.0, 0.25):
+        out = torch.zeros(3, device='cuda')
+        ops.kl_fwd(dev(mu), dev(lv), fb, out)
+        kpd = O.kl_per_dim(mu, lv)
+        floored = torch.maximum(kpd, torch.tensor(fb, dtype=torch.float64)) if fb > 0 else kpd
+        ref = torch.stack([floored.sum(1).mean(), kpd.sum(1).mean(), floored.mean()])
+        torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-6, atol=1e-6)
+        m64, l64 = mu.clone().requires_grad_(True), lv.clone().requires_grad_(True)
+        kp = O.kl_per_dim(m64, l64)
+        if fb > 0:
+            kp = torch.maximum(kp, torch.tensor(fb, dtype=torch.float64))
+        gm, gl = torch.autograd.grad(0.4 * 1.3 * kp.sum(1).mean(), [m64, l64])
+        dmu, dlv = ops.kl_bwd(dev(mu), dev(lv), torch.tensor([1.3], device='cuda'), 0.4, fb)
+        assert rel_err(dmu, gm) < 2e-6 and rel_err(dlv, gl) < 2e-6
+
+
+@pytest.mark.parametrize('B,Dc,Dm', [(4, 16, 16), (32, 128, 128), (9, 8, 20)])
+def test_independence(ops, B, Dc, Dm):
+    zc, zm = rnd(B, Dc, seed=7), rnd(B, Dm, seed=8) + 0.3 * rnd(B, 1, seed=9)
+    a, b = zc.clone().requires_grad_(True), zm.clone().requires_grad_(True)
+    an = (a - a.mean(0)) / (a.std(0) + 1e-8)
+    bn = (b - b.mean(0)) / (b.std(0) + 1e-8)
+    loss = ((an.t() @ bn / B) ** 2).mean()
+    ga, gb = torch.autograd.grad(1.7 * 0.02 * loss, [a, b])
+    out = torch.zeros(1, device='cuda')
+    ws = ops.indep_fwd(dev(zc), dev(zm), out)
+    assert abs(out.item() - loss.item()) < 2e-5 * abs(loss.item())
+    dzc, dzm = ops.indep_bwd(dev(zc), dev(zm), ws, torch.tensor([1.7], device='cuda'), 0.02)
+    assert rel_err(dzc, ga) < 5e-5 and rel_err(dzm, gb) < 5e-5
+
+
+# ------------------------------------------------------------------ GEMMs
+GEMM_SHAPES = [(32, 128, 512), (4, 32, 2048), (24, 64, 32), (608, 512, 8192 // 4), (130, 260, 36),
+               (640, 4096 // 4, 640), (256, 128, 4096), (1, 4, 4)]
+
+
+@pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
+def test_gemm_nt(ops, M, N, K):
+    a, b, bias = rnd(M, K, seed=10), rnd(N, K, seed=11), rnd(N, seed=12)
+    for act, with_bias in ((ops.ACT_NONE, False), (ops.ACT_LRELU, True)):
+        ref = a @ b.t()
+        if with_bias:
+            ref = ref + bias
+        if act == ops.ACT_LRELU:
+            ref = O.leaky_relu(ref)
+        got = ops.gemm_nt(dev(a), dev(b), dev(bias) if with_bias else None, act)
+        assert got.shape == (M, N)
+        assert rel_err(got, ref) < 2e-6, (M, N, K, act)
+
+
+@pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
+def test_gemm_nn_tn(ops, M, N, K):
+    a, b = rnd(M, K, seed=13), rnd(K, N, seed=14)
+    got = ops.gemm_nn(dev(a), dev(b))
+    assert rel_err(got, a @ b) < 2e-6
+    base = rnd(M, N, seed=15)
+    out = dev(base)
+    ops.gemm_nn(dev(a), dev(b), out=out, accumulate=True)
+    assert rel_err(out, base + a @ b) < 2e-6
+    if M % 4 == 0:
+        at = rnd(K, M, seed=16)
+        got = ops.gemm_tn(dev(at), dev(b))
+        assert rel_err(got, at.t() @ b) < 2e-6
+        out = dev(base)
+        ops.gemm_tn(dev(at), dev(b), out=out, accumulate=True)
+        assert rel_err(out, base + at.t() @ b) < 2e-6
+
+
+def test_gemm_strided_views(ops):
+    # operands that are column slices of wider matrices (row stride != width)
+    big = dev(rnd(40, 96, seed=17))
+    a = big[:, 32:64]
+    w = dev(rnd(48, 32, seed=18))
+    out_big = torch.zeros(40, 100, device='cuda')
+    ops.gemm_nt(a, w, None, ops.ACT_NONE, out=out_big[:, 4:52])
+    assert rel_err(out_big[:, 4:52], a.double().cpu() @ w.double().cpu().t()) < 2e-6
+    assert out_big[:, :4].abs().sum() == 0 and out_big[:, 52:].abs().sum() == 0
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from hipvae._lib import DvaeError
+    with pytest.raises(DvaeError):
+        ops.gemm_nt(dev(rnd(4, 6)), dev(rnd(8, 6)))          # K % 4 != 0
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(rnd(4, 8).float(), rnd(8, 8).float())     # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------ conv family
+def nhwc(t):   # NCHW -> NHWC
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [  # N, H, Cin, Cout
+    (3, 64, 1, 16), (2, 64, 1, 32), (5, 32, 16, 32), (3, 16, 32, 64), (4, 8, 64, 128), (9, 4, 8, 4),
+    (2, 8, 128, 256), (130, 4, 4, 8),
+]
+
+
+@pytest.mark.parametrize('N,H,Cin,Cout', CONV_CASES)
+def test_conv4s2_fwd(ops, N, H, Cin, Cout):
+    x = rnd(N, Cin, H, H, seed=20)
+    w = rnd(Cout, Cin, 4, 4, seed=21, scale=0.2)
+    use_affine = Cin > 1
+    sc, sh = 1 + 0.3 * rnd(Cin, seed=22), 0.2 * rnd(Cin, seed=23)
+    xin = O.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None]) if use_affine else x
+    ref = F.conv2d(xin, w, None, stride=2, padding=1)
+    wp = ops.pack_conv_w(dev(w))
+    y, stats, nparts = ops.conv4s2_fwd(dev(nhwc(x)), dev(sc) if use_affine else None,
+                                       dev(sh) if use_affine else None,
+                                       ops.ACT_LRELU if use_affine else ops.ACT_NONE, wp, True)
+    assert rel_err(nchw(y), ref) < 2e-6
+    s = stats.double().sum(0).cpu()
+    assert rel_err(s[0], ref.sum(dim=(0, 2, 3))) < 1e-5
+    assert rel_err(s[1], (ref ** 2).sum(dim=(0, 2, 3))) < 1e-5
+
+
+DECONV_CASES = [(3, 4, 64, 32), (2, 8, 32, 16), (3, 16, 16, 8), (2, 32, 8, 4), (6, 4, 256, 128), (70, 4, 4, 36)]
+
+
+@pytest.mark.parametrize('N,H,Cin,Cout', DECONV_CASES)
+def test_deconv4s2_fwd(ops, N, H, Cin, Cout):
+    x = rnd(N, Cin, H, H, seed=24)
+    w = rnd(Cin, Cout, 4, 4, seed=25, scale=0.2)
+    sc, sh = 1 + 0.3 * rnd(Cin, seed=26), 0.2 * rnd(Cin, seed=27)
+    xin = O.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None])
+    ref = F.conv_transpose2d(xin, w, None, stride=2, padding=1)
+    wp = ops.pack_deconv_w(dev(w))
+    y, stats, nparts = ops.deconv4s2_fwd(dev(nhwc(x)), dev(sc), dev(sh), ops.ACT_LRELU, wp, True)
+    assert rel_err(nchw(y), ref) < 2e-6
+    s = stats.double().sum(0).cpu()
+    assert rel_err(s[0], ref.sum(dim=(0, 2, 3))) < 1e-5
+    assert rel_err(s[1], (ref ** 2).sum(dim=(0, 2, 3))) < 1e-5
+    # identity load transform
+    y2, _, _ = ops.deconv4s2_fwd(dev(nhwc(x)), None, None, ops.ACT_NONE, wp, False)
+    assert rel_err(nchw(y2), F.conv_transpose2d(x, w, None, stride=2, padding=1)) < 2e-6
+
+
+def test_deconv_is_conv_data_gradient(ops):
+    # the transposed-conv kernel with a Conv2d weight gives that conv's input gradient
+    N, H, Cin, Cout = 3, 16, 8, 16
+    x = rnd(N, Cin, H, H, seed=28).requires_grad_(True)
+    w = rnd(Cout, Cin, 4, 4, seed=29, scale=0.2)
+    y = F.conv2d(x, w, None, stride=2, padding=1)
+    dy = rnd(*y.shape, seed=30)
+    (dx,) = torch.autograd.grad(y, x, dy)
+    wp = ops.pack_deconv_w(dev(w))      # [Kc=Cout][Nc=Cin]
+    got, _, _ = ops.deconv4s2_fwd(dev(nhwc(dy)), None, None, ops.ACT_NONE, wp, False)
+    assert rel_err(nchw(got), dx) < 2e-6
+
+
+WGRAD_CASES = [(3, 32, 16, 1), (4, 16, 32, 16), (3, 8, 64, 32), (2, 4, 128, 64), (5, 32, 32, 1), (2, 4, 8, 4),
+               (40, 16, 16, 8), (3, 2, 256, 128)]
+
+
+@pytest.mark.parametrize('N,Hs,C1,C2', WGRAD_CASES)
+def test_conv4s2_wgrad(ops, N, Hs, C1, C2):
+    # as a Conv2d weight gradient: P = dY [N,Hs,Hs,C1], Q = layer input [N,2Hs,2Hs,C2]
+    x = rnd(N, C2, 2 * Hs, 2 * Hs, seed=31)
+    dy = rnd(N, C1, Hs, Hs, seed=32)
+    use_affine = C2 > 1
+    sc, sh = 1 + 0.3 * rnd(C2, seed=33), 0.2 * rnd(C2, seed=34)
+    xin = O.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None]) if use_affine else x
+    w = torch.zeros(C1, C2, 4, 4, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xin, w, None, stride=2, padding=1)
+    (dw,) = torch.autograd.grad(y, w, dy)
+    got = ops.conv4s2_wgrad(dev(nhwc(dy)), None, None, ops.ACT_NONE, dev(nhwc(x)),
+                            dev(sc) if use_affine else None, dev(sh) if use_affine else None,
+                            ops.ACT_LRELU if use_affine else ops.ACT_NONE)
+    assert rel_err(got, dw) < 5e-6
+
+
+def test_wgrad_for_transposed_conv(ops):
+    # ConvTranspose2d weight gradient: P = layer input (with load transform), Q = dY
+    N, H, Cin, Cout = 3, 8, 16, 8
+    x = rnd(N, Cin, H, H, seed=35)
+    sc, sh = 1 + 0.3 * rnd(Cin, seed=36), 0.2 * rnd(Cin, seed=37)
+    xin = O.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None])
+    w = torch.zeros(Cin, Cout, 4, 4, dtype=torch.float64, requires_grad=True)
+    y = F.conv_transpose2d(xin, w, None, stride=2, padding=1)
+    dy = rnd(*y.shape, seed=38)
+    (dw,) = torch.autograd.grad(y, w, dy)
+    got = ops.conv4s2_wgrad(dev(nhwc(x)), dev(sc), dev(sh), ops.ACT_LRELU, dev(nhwc(dy)), None, None, ops.ACT_NONE)
+    assert rel_err(got, dw) < 5e-6
+
+
+@pytest.mark.parametrize('N,H,Cin', [(3, 32, 32), (2, 8, 4), (5, 16, 16)])
+def test_deconv_final(ops, N, H, Cin):
+    x = rnd(N, Cin, H, H, seed=39)
+    w = rnd(Cin, 1, 4, 4, seed=40, scale=0.3)
+    b = rnd(1, seed=41)
+    sc, sh = 1 + 0.3 * rnd(Cin, seed=42), 0.2 * rnd(Cin, seed=43)
+    xin = O.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None])
+    ref = torch.sigmoid(F.conv_transpose2d(xin, w, b, stride=2, padding=1))[:, 0]
+    got = ops.deconv4s2_final_fwd(dev(nhwc(x)), dev(sc), dev(sh), ops.ACT_LRELU, dev(w), dev(b), ops.ACT_SIGMOID)
+    torch.testing.assert_close(got.cpu().double(), ref, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ BatchNorm glue
+@pytest.mark.parametrize('M,C', [(4 * 32 * 32, 16), (640 * 16, 128), (37, 4), (2000, 512)])
+def test_bn_forward_backward(ops, M, C):
+    y = rnd(M, C, seed=44) * (1 + rnd(C, seed=45).abs()) + rnd(C, seed=46)
+    gamma, beta = 1 + 0.2 * rnd(C, seed=47), 0.1 * rnd(C, seed=48)
+    rm, rv = 0.1 * rnd(C, seed=49), 1 + 0.2 * rnd(C, seed=50).abs()
+    # statistics as the conv kernels would emit them: a few partial rows
+    parts = 5
+    chunks = y.chunk(parts, dim=0)
+    partials = torch.stack([torch.stack([c.sum(0), (c ** 2).sum(0)]) for c in chunks])
+    d_rm, d_rv = dev(rm), dev(rv)
+    nbt = torch.tensor(3, dtype=torch.int64, device='cuda')
+    scale, shift, mean, invstd = ops.bn_finalize(dev(partials), len(chunks), M, dev(gamma), dev(beta), d_rm, d_rv,
+                                                 nbt, 0.1, 1e-5)
+    mu = y.mean(0)
+    var = y.var(0, unbiased=False)
+    inv = 1 / torch.sqrt(var + 1e-5)
+    assert rel_err(mean, mu) < 1e-5 and rel_err(invstd, inv) < 1e-5
+    assert rel_err(scale, gamma * inv) < 1e-5 and rel_err(shift, beta - mu * gamma * inv) < 2e-5
+    assert rel_err(d_rm, 0.9 * rm + 0.1 * mu) < 1e-5
+    assert rel_err(d_rv, 0.9 * rv + 0.1 * y.var(0, unbiased=True)) < 1e-5
+    assert nbt.item() == 4
+    # eval affine
+    es, eh = ops.bn_eval_affine(dev(gamma), dev(beta), dev(rm), dev(rv), 1e-5)
+    assert rel_err(es, gamma / torch.sqrt(rv + 1e-5)) < 1e-6
+    assert rel_err(eh, beta - rm * gamma / torch.sqrt(rv + 1e-5)) < 1e-5
+    # materialised activation
+    act = ops.affine_act(dev(y), scale, shift, ops.ACT_LRELU)
+    ref_act = O.leaky_relu((y - mu) * inv * gamma + beta)
+    assert rel_err(act, ref_act) < 1e-5
+    # backward
+    y64 = y.clone().requires_grad_(True)
+    g64, b64 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    u = O.leaky_relu((y64 - y64.mean(0)) / torch.sqrt(y64.var(0, unbiased=False) + 1e-5) * g64 + b64)
+    du = rnd(M, C, seed=51)
+    dy, dg, db = torch.autograd.grad(u, [y64, g64, b64], du)
+    d_du = dev(du)
+    dgamma, dbeta = ops.bn_bwd(d_du, dev(y), scale, shift, mean, invstd, dev(gamma))
+    assert rel_err(dgamma, dg) < 2e-5 and rel_err(dbeta, db) < 2e-5
+    assert rel_err(d_du, dy) < 2e-5
+
+
+@pytest.mark.parametrize('M,N', [(32, 512), (640, 4096), (7, 4), (100, 36)])
+def test_bias_act_bwd(ops, M, N):
+    out = O.leaky_relu(rnd(M, N, seed=52))
+    dout = rnd(M, N, seed=53)
+    ref = torch.where(out > 0, dout, 0.2 * dout)
+    d = dev(dout)
+    db = ops.bias_act_bwd(d, dev(out), ops.ACT_LRELU, True)
+    assert rel_err(d, ref) < 1e-7 and rel_err(db, ref.sum(0)) < 1e-5
+    d = dev(dout)
+    db = ops.bias_act_bwd(d, None, ops.ACT_NONE, True)
+    assert rel_err(d, dout) < 1e-7 and rel_err(db, dout.sum(0)) < 1e-5
+
+
+def test_sigmoid_bwd(ops):
+    r = torch.sigmoid(rnd(3, 5, 64, 64, seed=54))
+    dr = rnd(3, 5, 64, 64, seed=55)
+    dl, db = ops.sigmoid_bwd(dev(dr), dev(r))
+    ref = dr * r * (1 - r)
+    assert rel_err(dl, ref) < 1e-6 and abs(db.item() - ref.sum().item()) < 1e-4 * abs(ref.sum().item()) + 1e-4
+
+
+# ------------------------------------------------------------------ LSTM steps
+@pytest.mark.parametrize('B,H,I,mode', [(4, 32, 32, 'xproj'), (32, 256, 512, 'xproj'), (5, 32, 32, 'x'),
+                                        (33, 64, 64, 'x'), (32, 256, 256, 'x'), (4, 32, 32, 'first')])
+def test_lstm_step_fwd(ops, B, H, I, mode):
+    w_ih, w_hh = rnd(4 * H, I, seed=60, scale=0.1), rnd(4 * H, H, seed=61, scale=0.1)
+    b_ih, b_hh = rnd(4 * H, seed=62, scale=0.1), rnd(4 * H, seed=63, scale=0.1)
+    x, h, c = rnd(B, I, seed=64), rnd(B, H, seed=65), rnd(B, H, seed=66)
+    if mode == 'first':
+        h = torch.zeros_like(h)
+        c = torch.zeros_like(c)
+    proj = x @ w_ih.t() + b_ih + b_hh
+    h2, c2 = O.lstm_cell(proj, h, c, w_hh)
+    gates = torch.empty(B, 4 * H, device='cuda')
+    # outputs written into column slices of wider buffers (row strides exercised)
+    hbuf = torch.zeros(B, 2 * H, device='cuda')
+    cbuf = torch.zeros(B, H, device='cuda')
+    if mode == 'x':
+        ops.lstm_step_fwd(None, dev(x), dev(w_ih), dev(h), dev(c), dev(w_hh), dev(b_ih), dev(b_hh), gates,
+                          hbuf[:, H:], cbuf)
+    elif mode == 'xproj':
+        ops.lstm_step_fwd(dev(proj), None, None, dev(h), dev(c), dev(w_hh), None, None, gates, hbuf[:, H:], cbuf)
+    else:
+        ops.lstm_step_fwd(dev(proj), None, None, None, None, dev(w_hh), None, None, gates, hbuf[:, H:], cbuf)
+    assert rel_err(hbuf[:, H:], h2) < 5e-6 and rel_err(cbuf, c2) < 5e-6
+    assert hbuf[:, :H].abs().sum() == 0
+    pre = proj + h @ w_hh.t()
+    i, f, g, o = pre.chunk(4, 1)
+    ref_g = torch.cat([torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)], 1)
+    assert rel_err(gates, ref_g) < 5e-6
+
+
+def test_lstm_step_bwd(ops):
+    B, H = 6, 32
+    w_hh, w_ih = rnd(4 * H, H, seed=67, scale=0.2), rnd(4 * H, H, seed=68, scale=0.2)
+    proj = rnd(B, 4 * H, seed=69)
+    h = rnd(B, H, seed=70).requires_grad_(True)
+    c = rnd(B, H, seed=71).requires_grad_(True)
+    p = proj.clone().requires_grad_(True)
+    h2, c2 = O.lstm_cell(p, h, c, w_hh)
+    dh2, dc2 = rnd(B, H, seed=72), rnd(B, H, seed=73)
+    dp, dh, dc = torch.autograd.grad([h2, c2], [p, h, c], [dh2, dc2])
+    pre = proj + h.detach() @ w_hh.t()
+    i, f, g, o = pre.chunk(4, 1)
+    gates = torch.cat([torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)], 1)
+    dgates = torch.empty(B, 4 * H, device='cuda')
+    dcp = torch.empty(B, H, device='cuda')
+    ops.lstm_step_bwd_pointwise(dev(dh2), dev(dc2), dev(gates), dev(c.detach()), dev(c2.detach()), dgates, dcp)
+    assert rel_err(dgates, dp) < 5e-6 and rel_err(dcp, dc) < 5e-6
+    out = torch.empty(B, H, device='cuda')
+    ops.skinny_gemm_nn(dgates, dev(w_hh), None, out, False)
+    assert rel_err(out, dh) < 5e-6
+    ops.skinny_gemm_nn(dgates, dev(w_hh), dev(w_ih), out, True)
+    assert rel_err(out, dh + dp @ w_hh + dp @ w_ih) < 5e-6
+
+
+@pytest.mark.parametrize('B,N,K', [(32, 256, 1024), (70, 36, 132), (1, 4, 4)])
+def test_skinny_gemm(ops, B, N, K):
+    a, w = rnd(B, K, seed=74), rnd(K, N, seed=75)
+    out = torch.empty(B, N, device='cuda')
+    ops.skinny_gemm_nn(dev(a), dev(w), None, out, False)
+    assert rel_err(out, a @ w) < 2e-6
+
+
+# ------------------------------------------------------------------ optimiser
+def test_grad_norm_clip_adam(ops):
+    g = torch.Generator().manual_seed(80)
+    shapes = [(17,), (64, 33), (1,), (256, 128, 4, 4), (5, 3)] * 12      # 60 tensors: more than one launch
+    params = [torch.randn(s, generator=g) for s in shapes]
+    grads = [torch.randn(s, generator=g) * 3 for s in shapes]
+    m = [torch.randn(s, generator=g) * 0.1 for s in shapes]
+    v = [torch.rand(s, generator=g) * 0.1 for s in shapes]
+    total, clipped = O.clip_grad_norm([x.double() for x in grads], 5.0)
+    out = torch.zeros(2, device='cuda')
+    dg = [dev(x) for x in grads]
+    ops.grad_norm(dg, 5.0, out)
+    assert abs(out[0].item() - total.item()) < 1e-5 * total.item()
+    coef = min(1.0, 5.0 / (total.item() + 1e-6))
+    assert abs(out[1].item() - coef) < 1e-5 * coef
+    dp, dm, dv = [dev(x) for x in params], [dev(x) for x in m], [dev(x) for x in v]
+    step, lr, b1, b2, eps, wd = 7, 3e-4, 0.9, 0.999, 1e-8, 1e-5
+    ops.adam_step(dp, dg, dm, dv, lr, b1, b2, eps, wd, 1 - b1 ** step, 1 - b2 ** step, out[1:2])
+    for i in range(len(shapes)):
+        p2, m2, v2 = O.adam_step(params[i].double(), clipped[i], m[i].double(), v[i].double(), step, lr, b1, b2,
+                                 eps, wd)
+        assert rel_err(dp[i], p2) < 1e-6 and rel_err(dm[i], m2) < 1e-6 and rel_err(dv[i], v2) < 1e-6
+    # in-place scaling of gradients by the device coefficient
+    ops.scale_tensors(dg, out[1:2])
+    for i in range(len(shapes)):
+        assert rel_err(dg[i], clipped[i]) < 1e-6
+    # no clipping when max_norm <= 0
+    ops.grad_norm(dg, 0.0, out)
+    assert out[1].item() == 1.0
