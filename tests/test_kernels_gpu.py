@@ -94,7 +94,7 @@ def test_reparam_and_kl(ops):
     assert rel_err(z, O.reparameterize(mu, lv, eps)) < 1e-6
     dz = rnd(B, D, seed=6)
     dmu, dlv = ops.reparam_bwd(dev(dz), dev(lv), dev(eps))
-    assert rel_err(dmu, dz) == 0
+    assert rel_err(dmu, dz) < 1e-7
     assert rel_err(dlv, dz * eps * 0.5 * torch.exp(0.5 * lv)) < 1e-6
     for fb in (0.0, 0.25):
         out = torch.zeros(3, device='cuda')
