@@ -754,3 +754,61 @@ extern "C" int dvae_sigmoid_bwd_f32(const float* drecon, const float* recon, flo
   }
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// layout helpers: 3-D permutation (weight re-ordering between the reference's NCHW flatten order and
+// the NHWC order the kernels use; batch-major <-> time-major sequences) and a weighted sum of scalars
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+permute3_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t D0, int64_t D1, int64_t D2, int p0,
+                int p1, int p2) {
+  // out dims = (D[p0], D[p1], D[p2]); threads walk the output linearly
+  const int64_t d[3] = {D0, D1, D2};
+  const int64_t istr[3] = {D1 * D2, D2, 1};
+  const int64_t o1 = d[p1], o2 = d[p2];
+  const int64_t total = D0 * D1 * D2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t c = i % o2, b = (i / o2) % o1, a = i / (o2 * o1);
+    out[i] = in[a * istr[p0] + b * istr[p1] + c * istr[p2]];
+  }
+}
+
+extern "C" int dvae_permute3_f32(const float* in, float* out, int64_t D0, int64_t D1, int64_t D2, int p0, int p1,
+                                 int p2, dvae_stream_t stream) {
+  DVAE_REQUIRE(D0 > 0 && D1 > 0 && D2 > 0, "permute3: empty");
+  DVAE_REQUIRE(p0 >= 0 && p0 < 3 && p1 >= 0 && p1 < 3 && p2 >= 0 && p2 < 3 && p0 != p1 && p0 != p2 && p1 != p2,
+               "permute3: (%d,%d,%d) is not a permutation", p0, p1, p2);
+  int64_t nb = ceil_div64(D0 * D1 * D2, 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(permute3_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), in, out, D0, D1, D2, p0, p1, p2);
+  DVAE_LAUNCH_CHECK("permute3");
+  return 0;
+}
+
+struct WSumArgs {
+  const float* src[8];
+  float coef[8];
+  int n;
+};
+
+__global__ void weighted_sum_kernel(WSumArgs a, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < a.n; ++i) s += a.coef[i] * a.src[i][0];
+    out[0] = s;
+  }
+}
+
+extern "C" int dvae_weighted_sum_f32(int n, const float* const* terms, const float* coefs, float* out,
+                                     dvae_stream_t stream) {
+  DVAE_REQUIRE(n > 0 && n <= 8, "weighted_sum: 1..8 terms (got %d)", n);
+  WSumArgs a;
+  a.n = n;
+  for (int i = 0; i < n; ++i) {
+    a.src[i] = terms[i];
+    a.coef[i] = coefs[i];
+  }
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(64), 0, ST(stream), a, out);
+  DVAE_LAUNCH_CHECK("weighted_sum");
+  return 0;
+}

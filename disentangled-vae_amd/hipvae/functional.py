@@ -1,0 +1,458 @@
+"""Autograd building blocks of the MI355X hot path.
+
+Each Function covers one fusion region of the network and runs only HIP kernels from
+libdvae_hip.so in both directions:
+
+  EncoderCNN   [Conv(k4,s2,p1) -> BN -> LeakyReLU]* -> flatten -> Linear -> LeakyReLU
+  DecoderCNN   Linear -> LeakyReLU -> [ConvT -> BN -> LeakyReLU]* -> ConvT(bias) -> sigmoid
+  Linear       x W^T + b (+ LeakyReLU)
+  LSTMEncoder  (bi)directional multi-layer LSTM over a sequence, returns the final hidden states
+  LSTMDecoder  autoregressive multi-layer LSTM (x_t = top-layer h_{t-1})
+  Reparam      z = mu + eps * exp(logvar / 2)
+
+Activations are NHWC with frames folded into the leading dimension; a layer's BatchNorm +
+LeakyReLU is never materialised between conv layers: the conv kernel writes the raw output plus
+per-channel partial sums, a finalize kernel folds the statistics into (scale, shift), and the next
+kernel applies them while loading.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import ops
+
+Tensor = torch.Tensor
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _need_gpu(t: Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: input is on {t.device}; this package runs on the GPU only "
+                           "(there is no CPU fallback)")
+
+
+class BNState:
+    """Non-tensor handle for a BatchNorm layer's buffers (updated in place by the kernels)."""
+
+    def __init__(self, running_mean: Tensor, running_var: Tensor, num_batches_tracked: Tensor):
+        self.rm, self.rv, self.nbt = running_mean, running_var, num_batches_tracked
+
+
+def _bn_affine(stats, nparts, M, gamma, beta, bn: BNState, training: bool):
+    if training:
+        return ops.bn_finalize(stats, nparts, M, gamma, beta, bn.rm, bn.rv, bn.nbt, BN_MOMENTUM, BN_EPS)
+    sc, sh = ops.bn_eval_affine(gamma, beta, bn.rm, bn.rv, BN_EPS)
+    return sc, sh, None, None
+
+
+# =================================================================================================
+class EncoderCNN(torch.autograd.Function):
+    """CNNEncoder / LightCNNEncoder of the reference (models/encoders.py:11-97)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, training: bool, bns: List[BNState], fc_w: Tensor, fc_b: Tensor, *wgb: Tensor):
+        # x: [N, H, W, Cin] NHWC; wgb = conv weights (L), then BN gammas (L), then BN betas (L)
+        _need_gpu(x, 'EncoderCNN')
+        L = len(bns)
+        conv_w, gammas, betas = wgb[:L], wgb[L:2 * L], wgb[2 * L:3 * L]
+        ys, affs = [], []
+        cur, sc, sh, act = x.contiguous(), None, None, ops.ACT_NONE
+        for l in range(L):
+            wp = ops.pack_conv_w(conv_w[l].detach())
+            y, stats, nparts = ops.conv4s2_fwd(cur, sc, sh, act, wp, training)
+            M = y.numel() // y.shape[-1]
+            aff = _bn_affine(stats, nparts, M, gammas[l].detach(), betas[l].detach(), bns[l], training)
+            ys.append(y)
+            affs.append(aff)
+            cur, sc, sh, act = y, aff[0], aff[1], ops.ACT_LRELU
+        u = ops.affine_act(cur, sc, sh, ops.ACT_LRELU)
+        N, h, w, C = u.shape
+        S = h * w
+        F_out = fc_w.shape[0]
+        if fc_w.shape[1] != C * S:
+            raise RuntimeError(f"encoder fc expects {fc_w.shape[1]} inputs but the conv stack produced {C * S}")
+        # reference flattens NCHW (c,h,w); ours is (h,w,c): permute the weight columns instead
+        w_perm = ops.permute3(fc_w.detach(), (F_out, C, S), (0, 2, 1)).view(F_out, S * C)
+        u_flat = u.view(N, S * C)
+        feat = ops.gemm_nt(u_flat, w_perm, fc_b.detach(), ops.ACT_LRELU)
+        if training:
+            ctx.save_for_backward(x, u_flat, w_perm, feat, *ys, *conv_w)
+            ctx.affs = affs
+            ctx.gammas = [g.detach() for g in gammas]
+            ctx.L = L
+            ctx.fc_shape = (F_out, C, S)
+        else:
+            ctx.L = -1
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat: Tensor):
+        if ctx.L < 0:
+            raise RuntimeError("EncoderCNN: backward is only implemented for training mode (batch statistics)")
+        L = ctx.L
+        saved = ctx.saved_tensors
+        x, u_flat, w_perm, feat = saved[:4]
+        ys, conv_w = saved[4:4 + L], saved[4 + L:4 + 2 * L]
+        affs = ctx.affs
+        F_out, C, S = ctx.fc_shape
+        dpre = dfeat.contiguous().clone()
+        d_fc_b = ops.bias_act_bwd(dpre, feat, ops.ACT_LRELU, True)
+        d_wperm = ops.gemm_tn(dpre, u_flat)                       # [F, S*C]
+        d_fc_w = ops.permute3(d_wperm, (F_out, S, C), (0, 2, 1)).view(F_out, C * S)
+        du = ops.gemm_nn(dpre, w_perm).view(ys[-1].shape)        # grad wrt post-activation of last conv
+        d_conv, d_gamma, d_beta = [None] * L, [None] * L, [None] * L
+        for l in range(L - 1, -1, -1):
+            sc, sh, mean, invstd = affs[l]
+            d_gamma[l], d_beta[l] = ops.bn_bwd(du, ys[l], sc, sh, mean, invstd, ctx.gammas[l])
+            dy = du                                              # now dL/d(raw conv output)
+            if l > 0:
+                psc, psh = affs[l - 1][0], affs[l - 1][1]
+                d_conv[l] = ops.conv4s2_wgrad(dy, None, None, ops.ACT_NONE, ys[l - 1], psc, psh, ops.ACT_LRELU)
+                wpd = ops.pack_deconv_w(conv_w[l])
+                du, _, _ = ops.deconv4s2_fwd(dy, None, None, ops.ACT_NONE, wpd, False)
+            else:
+                d_conv[0] = ops.conv4s2_wgrad(dy, None, None, ops.ACT_NONE, x, None, None, ops.ACT_NONE)
+        return (None, None, None, d_fc_w, d_fc_b, *d_conv, *d_gamma, *d_beta)
+
+
+# =================================================================================================
+class DecoderCNN(torch.autograd.Function):
+    """CNNDecoder of the reference (models/decoders.py:11-70); returns frames [N, 1, 2^k*4, ...]."""
+
+    @staticmethod
+    def forward(ctx, feat: Tensor, training: bool, bns: List[BNState], fc_w: Tensor, fc_b: Tensor,
+                final_w: Tensor, final_b: Tensor, *wgb: Tensor):
+        _need_gpu(feat, 'DecoderCNN')
+        L = len(bns)
+        dec_w, gammas, betas = wgb[:L], wgb[L:2 * L], wgb[2 * L:3 * L]
+        N, Kin = feat.shape
+        C0 = dec_w[0].shape[0] if L > 0 else final_w.shape[0]
+        S = 16
+        if fc_w.shape[0] != C0 * S:
+            raise RuntimeError("decoder fc output does not match channels[0]*4*4")
+        if final_w.shape[1] != 1:
+            raise RuntimeError("the final transposed convolution kernel supports one output channel")
+        # rows of the fc weight are (c,h,w) in the reference; ours are (h,w,c)
+        w_perm = ops.permute3(fc_w.detach(), (C0, S, Kin), (1, 0, 2)).view(S * C0, Kin)
+        b_perm = ops.permute3(fc_b.detach(), (C0, S, 1), (1, 0, 2)).view(S * C0)
+        feat_c = feat.contiguous()
+        h0 = ops.gemm_nt(feat_c, w_perm, b_perm, ops.ACT_LRELU)   # [N, 4*4*C0] == NHWC [N,4,4,C0]
+        cur = h0.view(N, 4, 4, C0)
+        sc, sh, act = None, None, ops.ACT_NONE
+        ys, affs = [], []
+        for l in range(L):
+            wpd = ops.pack_deconv_w(dec_w[l].detach())
+            y, stats, nparts = ops.deconv4s2_fwd(cur, sc, sh, act, wpd, training)
+            M = y.numel() // y.shape[-1]
+            aff = _bn_affine(stats, nparts, M, gammas[l].detach(), betas[l].detach(), bns[l], training)
+            ys.append(y)
+            affs.append(aff)
+            cur, sc, sh, act = y, aff[0], aff[1], ops.ACT_LRELU
+        recon = ops.deconv4s2_final_fwd(cur, sc, sh, act, final_w.detach(), final_b.detach(), ops.ACT_SIGMOID)
+        recon = recon.view(N, 1, recon.shape[1], recon.shape[2])
+        if training:
+            ctx.save_for_backward(feat_c, w_perm, h0, recon, final_w, *ys, *dec_w)
+            ctx.affs = affs
+            ctx.gammas = [g.detach() for g in gammas]
+            ctx.L = L
+            ctx.dims = (C0, S, Kin)
+        else:
+            ctx.L = -1
+        return recon
+
+    @staticmethod
+    def backward(ctx, drecon: Tensor):
+        if ctx.L < 0:
+            raise RuntimeError("DecoderCNN: backward is only implemented for training mode (batch statistics)")
+        L = ctx.L
+        saved = ctx.saved_tensors
+        feat, w_perm, h0, recon, final_w = saved[:5]
+        ys, dec_w = saved[5:5 + L], saved[5 + L:5 + 2 * L]
+        affs = ctx.affs
+        C0, S, Kin = ctx.dims
+        N = feat.shape[0]
+        dlogit, d_final_b = ops.sigmoid_bwd(drecon.contiguous(), recon)
+        Ho, Wo = recon.shape[2], recon.shape[3]
+        dlogit4 = dlogit.view(N, Ho, Wo, 1)
+        # input of the final layer: last raw deconv output with its BN+LReLU, or h0 itself when L == 0
+        if L > 0:
+            xin, xsc, xsh, xact = ys[-1], affs[-1][0], affs[-1][1], ops.ACT_LRELU
+        else:
+            xin, xsc, xsh, xact = h0.view(N, 4, 4, C0), None, None, ops.ACT_NONE
+        d_final_w = ops.conv4s2_wgrad(xin, xsc, xsh, xact, dlogit4, None, None, ops.ACT_NONE)
+        # the [Cin][1][4][4] weight is already the packed [Cout_c=Cin][4][4][Cin_c=1] conv layout
+        du, _, _ = ops.conv4s2_fwd(dlogit4, None, None, ops.ACT_NONE, final_w.contiguous(), False)
+        d_dec, d_gamma, d_beta = [None] * L, [None] * L, [None] * L
+        for l in range(L - 1, -1, -1):
+            sc, sh, mean, invstd = affs[l]
+            d_gamma[l], d_beta[l] = ops.bn_bwd(du, ys[l], sc, sh, mean, invstd, ctx.gammas[l])
+            dy = du
+            if l > 0:
+                pin, psc, psh, pact = ys[l - 1], affs[l - 1][0], affs[l - 1][1], ops.ACT_LRELU
+            else:
+                pin, psc, psh, pact = h0.view(N, 4, 4, C0), None, None, ops.ACT_NONE
+            d_dec[l] = ops.conv4s2_wgrad(pin, psc, psh, pact, dy, None, None, ops.ACT_NONE)
+            wp = ops.pack_conv_w(dec_w[l])        # [Cin_d][4][4][Cout_d]: the adjoint is a plain conv
+            du, _, _ = ops.conv4s2_fwd(dy, None, None, ops.ACT_NONE, wp, False)
+        dpre = du.view(N, S * C0)                  # grad wrt h0 (post-LeakyReLU), freshly allocated
+        d_bperm = ops.bias_act_bwd(dpre, h0, ops.ACT_LRELU, True)
+        d_wperm = ops.gemm_tn(dpre, feat)          # [S*C0, Kin]
+        d_fc_w = ops.permute3(d_wperm, (S, C0, Kin), (1, 0, 2)).view(C0 * S, Kin)
+        d_fc_b = ops.permute3(d_bperm, (S, C0, 1), (1, 0, 2)).view(C0 * S)
+        dfeat = ops.gemm_nn(dpre, w_perm)
+        return (dfeat, None, None, d_fc_w, d_fc_b, d_final_w, d_final_b, *d_dec, *d_gamma, *d_beta)
+
+
+# =================================================================================================
+class Linear(torch.autograd.Function):
+    """nn.Linear (+ optional LeakyReLU(0.2)) on the f32-MFMA GEMM."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, b: Optional[Tensor], act: int):
+        _need_gpu(x, 'Linear')
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).contiguous()
+        out = ops.gemm_nt(x2, w.detach().contiguous(), None if b is None else b.detach(), act)
+        ctx.save_for_backward(x2, w, out if act != ops.ACT_NONE else None)
+        ctx.act = act
+        ctx.has_bias = b is not None
+        ctx.in_shape = shape
+        return out.view(*shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        x2, w, out = ctx.saved_tensors
+        d = dout.reshape(-1, w.shape[0]).contiguous()
+        if ctx.act != ops.ACT_NONE:
+            d = d.clone()
+        db = ops.bias_act_bwd(d, out, ctx.act, ctx.has_bias)
+        dw = ops.gemm_tn(d, x2) if ctx.needs_input_grad[1] else None
+        dx = ops.gemm_nn(d, w.contiguous()).view(ctx.in_shape) if ctx.needs_input_grad[0] else None
+        return dx, dw, db, None
+
+
+def linear(x, w, b, act=ops.ACT_NONE):
+    return Linear.apply(x, w, b, act)
+
+
+class Reparam(torch.autograd.Function):
+    """z = mu + eps * exp(logvar / 2)  (models/encoders.py:211-213 with the draw made explicit)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        _need_gpu(mu, 'Reparam')
+        mu, logvar, eps = mu.contiguous(), logvar.contiguous(), eps.contiguous()
+        ctx.save_for_backward(logvar, eps)
+        return ops.reparam_fwd(mu, logvar, eps)
+
+    @staticmethod
+    def backward(ctx, dz):
+        logvar, eps = ctx.saved_tensors
+        dmu, dlv = ops.reparam_bwd(dz.contiguous(), logvar, eps)
+        return dmu, dlv, None
+
+
+# =================================================================================================
+def _zeros(*shape, like: Tensor):
+    return torch.zeros(*shape, dtype=torch.float32, device=like.device)
+
+
+def _empty(*shape, like: Tensor):
+    return torch.empty(*shape, dtype=torch.float32, device=like.device)
+
+
+class LSTMEncoder(torch.autograd.Function):
+    """nn.LSTM(batch_first, bidirectional, num_layers) from zero state; returns cat of the last
+    layer's final hidden state per direction (models/encoders.py:156-173).
+
+    Weights come flat, per layer and direction: w_ih, w_hh, b_ih, b_hh.  Internally time-major.
+    """
+
+    @staticmethod
+    def forward(ctx, x: Tensor, num_layers: int, bidirectional: bool, *weights: Tensor):
+        _need_gpu(x, 'LSTMEncoder')
+        B, T, I0 = x.shape
+        D = 2 if bidirectional else 1
+        H = weights[1].shape[1]
+        inp = ops.permute3(x.contiguous(), (B, T, I0), (1, 0, 2))       # [T, B, I]
+        layers = []
+        for l in range(num_layers):
+            I = inp.shape[2]
+            hseq = _empty(T, B, D * H, like=x)
+            cseq = _empty(D, T, B, H, like=x)
+            gates = _empty(D, T, B, 4 * H, like=x)
+            for d in range(D):
+                w_ih, w_hh, b_ih, b_hh = [w.detach() for w in weights[(l * D + d) * 4:(l * D + d) * 4 + 4]]
+                xproj = ops.gemm_nt(inp.view(T * B, I), w_ih.contiguous()).view(T, B, 4 * H)
+                order = range(T - 1, -1, -1) if d == 1 else range(T)
+                prev = None
+                for t in order:
+                    h_prev = None if prev is None else hseq[prev][:, d * H:(d + 1) * H]
+                    c_prev = None if prev is None else cseq[d, prev]
+                    ops.lstm_step_fwd(xproj[t], None, None, h_prev, c_prev, w_hh.contiguous(), b_ih, b_hh,
+                                      gates[d, t], hseq[t][:, d * H:(d + 1) * H], cseq[d, t])
+                    prev = t
+            layers.append((inp, hseq, cseq, gates))
+            inp = hseq
+        last = layers[-1][1]
+        if bidirectional:
+            final = torch.cat([last[T - 1][:, :H], last[0][:, H:]], dim=1)
+        else:
+            final = last[T - 1].clone()
+        ctx.layers = layers
+        ctx.cfg = (B, T, I0, D, H, num_layers)
+        ctx.save_for_backward(*weights)
+        return final
+
+    @staticmethod
+    def backward(ctx, dfinal: Tensor):
+        B, T, I0, D, H, L = ctx.cfg
+        weights = ctx.saved_tensors
+        grads = [None] * len(weights)
+        dfinal = dfinal.contiguous()
+        dout = None                                    # gradient wrt this layer's output sequence
+        for l in range(L - 1, -1, -1):
+            inp, hseq, cseq, gates = ctx.layers[l]
+            I = inp.shape[2]
+            dh = dout if dout is not None else _zeros(T, B, D * H, like=dfinal)
+            if l == L - 1:
+                dh[T - 1][:, :H] += dfinal[:, :H]
+                if D == 2:
+                    dh[0][:, H:] += dfinal[:, H:]
+            dinp = None
+            for d in range(D):
+                k = (l * D + d) * 4
+                w_ih, w_hh = weights[k].contiguous(), weights[k + 1].contiguous()
+                dg = _empty(T, B, 4 * H, like=dfinal)
+                dc = [_empty(B, H, like=dfinal), _empty(B, H, like=dfinal)]
+                order = list(range(T - 1, -1, -1)) if d == 1 else list(range(T))
+                sl = slice(d * H, (d + 1) * H)
+                for i in range(T - 1, -1, -1):                # walk the recurrence backwards
+                    t = order[i]
+                    tp = order[i - 1] if i > 0 else None
+                    ops.lstm_step_bwd_pointwise(dh[t][:, sl], None if i == T - 1 else dc[(i + 1) & 1], gates[d, t],
+                                                None if tp is None else cseq[d, tp], cseq[d, t], dg[t], dc[i & 1])
+                    if tp is not None:
+                        ops.skinny_gemm_nn(dg[t], w_hh, None, dh[tp][:, sl], True)
+                dg2 = dg.view(T * B, 4 * H)
+                grads[k] = ops.gemm_tn(dg2, inp.view(T * B, I))                      # dW_ih
+                # dW_hh = sum_t dG_t^T h_prev(t): forward uses h[t-1], reverse uses h[t+1]
+                hs2 = hseq.view(T * B, D * H)[:, sl]
+                if T > 1:
+                    if d == 0:
+                        grads[k + 1] = ops.gemm_tn(dg2[B:], hs2[:(T - 1) * B])
+                    else:
+                        grads[k + 1] = ops.gemm_tn(dg2[:(T - 1) * B], hs2[B:])
+                else:
+                    grads[k + 1] = torch.zeros_like(w_hh)
+                db = ops.bias_act_bwd(dg2, None, ops.ACT_NONE, True)
+                grads[k + 2] = db
+                grads[k + 3] = db.clone()
+                if l > 0 or ctx.needs_input_grad[0]:
+                    if dinp is None:
+                        dinp = ops.gemm_nn(dg2, w_ih)
+                    else:
+                        ops.gemm_nn(dg2, w_ih, out=dinp, accumulate=True)
+            dout = None if dinp is None else dinp.view(T, B, I)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.permute3(dout, (T, B, I0), (1, 0, 2))
+        ctx.layers = None
+        return (dx, None, None, *grads)
+
+
+class LSTMDecoder(torch.autograd.Function):
+    """Autoregressive decoder recurrence (models/decoders.py:118-134, :253-269).
+
+    h0c0_h, h0c0_c: [B, L*H] (fc_hidden / fc_cell outputs; layer l seeds from columns l*H:(l+1)*H);
+    initial_input [1, H]; weights per layer: w_ih, w_hh, b_ih, b_hh.  Returns states [B, T, H].
+    """
+
+    @staticmethod
+    def forward(ctx, h0: Tensor, c0: Tensor, init: Tensor, T: int, num_layers: int, *weights: Tensor):
+        _need_gpu(h0, 'LSTMDecoder')
+        B = h0.shape[0]
+        L = num_layers
+        H = h0.shape[1] // L
+        h0, c0 = h0.contiguous(), c0.contiguous()
+        init_c = init.detach().contiguous()
+        hs = _empty(L, T, B, H, like=h0)
+        cs = _empty(L, T, B, H, like=h0)
+        gates = _empty(L, T, B, 4 * H, like=h0)
+        w = [t.detach().contiguous() for t in weights]
+        x0 = init_c.expand(B, H)                      # row stride 0: every row reads the same vector
+        for t in range(T):
+            for l in range(L):
+                if l == 0:
+                    x = x0 if t == 0 else hs[L - 1, t - 1]
+                else:
+                    x = hs[l - 1, t]
+                h_prev = h0[:, l * H:(l + 1) * H] if t == 0 else hs[l, t - 1]
+                c_prev = c0[:, l * H:(l + 1) * H] if t == 0 else cs[l, t - 1]
+                ops.lstm_step_fwd(None, x, w[4 * l], h_prev, c_prev, w[4 * l + 1], w[4 * l + 2], w[4 * l + 3],
+                                  gates[l, t], hs[l, t], cs[l, t])
+        states = ops.permute3(hs[L - 1], (T, B, H), (1, 0, 2))         # [B, T, H]
+        ctx.save_for_backward(h0, c0, init_c, hs, cs, gates, *weights)
+        ctx.cfg = (B, T, L, H)
+        return states
+
+    @staticmethod
+    def backward(ctx, dstates: Tensor):
+        B, T, L, H = ctx.cfg
+        saved = ctx.saved_tensors
+        h0, c0, init_c, hs, cs, gates = saved[:6]
+        weights = [t.contiguous() for t in saved[6:]]
+        dhs = _zeros(L, T, B, H, like=h0)
+        dhs[L - 1] = ops.permute3(dstates.contiguous(), (B, T, H), (1, 0, 2))
+        dg = _empty(L, T, B, 4 * H, like=h0)
+        dh0 = _empty(B, L * H, like=h0)
+        dc0 = _empty(B, L * H, like=h0)
+        dcbuf = [[_empty(B, H, like=h0), _empty(B, H, like=h0)] for _ in range(L)]
+        dx0 = _empty(B, H, like=h0)
+        for t in range(T - 1, -1, -1):
+            for l in range(L - 1, -1, -1):
+                w_ih, w_hh = weights[4 * l], weights[4 * l + 1]
+                c_prev = c0[:, l * H:(l + 1) * H] if t == 0 else cs[l, t - 1]
+                dc_in = None if t == T - 1 else dcbuf[l][(t + 1) & 1]
+                dc_out = dc0[:, l * H:(l + 1) * H] if t == 0 else dcbuf[l][t & 1]
+                ops.lstm_step_bwd_pointwise(dhs[l, t], dc_in, gates[l, t], c_prev, cs[l, t], dg[l, t], dc_out)
+                # recurrent path -> h_{t-1} of this layer
+                rec_target = dh0[:, l * H:(l + 1) * H] if t == 0 else dhs[l, t - 1]
+                rec_acc = t > 0
+                # input path -> layer below at the same step, or the top layer's previous output
+                if l > 0:
+                    ops.skinny_gemm_nn(dg[l, t], w_hh, None, rec_target, rec_acc)
+                    ops.skinny_gemm_nn(dg[l, t], w_ih, None, dhs[l - 1, t], True)
+                elif t > 0:
+                    if L == 1:
+                        ops.skinny_gemm_nn(dg[0, t], w_hh, w_ih, rec_target, True)
+                    else:
+                        ops.skinny_gemm_nn(dg[0, t], w_hh, None, rec_target, True)
+                        ops.skinny_gemm_nn(dg[0, t], w_ih, None, dhs[L - 1, t - 1], True)
+                else:
+                    ops.skinny_gemm_nn(dg[0, 0], w_hh, None, rec_target, False)
+                    ops.skinny_gemm_nn(dg[0, 0], w_ih, None, dx0, False)
+        dinit = ops.bias_act_bwd(dx0, None, ops.ACT_NONE, True).view(1, H)
+        grads = [None] * (4 * L)
+        for l in range(L):
+            dg2 = dg[l].view(T * B, 4 * H)
+            hs2 = hs[l].view(T * B, H)
+            # dW_hh: h_prev(t) = hs[l, t-1] for t >= 1, h0 slice for t = 0
+            dw_hh = ops.gemm_tn(dg2[:B], h0[:, l * H:(l + 1) * H])
+            if T > 1:
+                ops.gemm_tn(dg2[B:], hs2[:(T - 1) * B], out=dw_hh, accumulate=True)
+            grads[4 * l + 1] = dw_hh
+            if l > 0:
+                grads[4 * l] = ops.gemm_tn(dg2, hs[l - 1].view(T * B, H))
+            else:
+                # x_0 = initial_input for every row: outer(colsum(dG_0), init)
+                colsum0 = ops.bias_act_bwd(dg2[:B], None, ops.ACT_NONE, True).view(1, 4 * H)
+                dw_ih = ops.gemm_tn(colsum0, init_c.view(1, H))
+                if T > 1:
+                    ops.gemm_tn(dg2[B:], hs[L - 1].view(T * B, H)[:(T - 1) * B], out=dw_ih, accumulate=True)
+                grads[0] = dw_ih
+            db = ops.bias_act_bwd(dg2, None, ops.ACT_NONE, True)
+            grads[4 * l + 2] = db
+            grads[4 * l + 3] = db.clone()
+        return (dh0, dc0, dinit, None, None, *grads)

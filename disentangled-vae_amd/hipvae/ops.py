@@ -199,6 +199,25 @@ def sigmoid_bwd(drecon: Tensor, recon: Tensor, want_bias: bool = True):
     return dl, db
 
 
+# ---------------------------------------------------------------------------- layout helpers
+def permute3(x: Tensor, dims: Tuple[int, int, int], perm: Tuple[int, int, int]) -> Tensor:
+    """x viewed as contiguous [D0,D1,D2] -> contiguous x.permute(perm)."""
+    _chk(x)
+    D0, D1, D2 = dims
+    assert x.numel() == D0 * D1 * D2
+    out = torch.empty(dims[perm[0]], dims[perm[1]], dims[perm[2]], dtype=torch.float32, device=x.device)
+    check(lib.dvae_permute3_f32(_p(x), _p(out), D0, D1, D2, perm[0], perm[1], perm[2], _stream()), 'permute3')
+    return out
+
+
+def weighted_sum(terms: Sequence[Tensor], coefs: Sequence[float], out: Tensor):
+    """out[0] = sum_i coefs[i] * terms[i][0] for up to 8 device scalars."""
+    n = len(terms)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in terms])
+    cf = (ctypes.c_float * n)(*[float(c) for c in coefs])
+    check(lib.dvae_weighted_sum_f32(n, ptrs, cf, _p(out), _stream()), 'weighted_sum')
+
+
 # ---------------------------------------------------------------------------- GEMMs
 def _rows(t: Tensor) -> Tuple[int, int]:
     """(rows, row stride) of a 2-D tensor whose last dim is contiguous."""

@@ -107,6 +107,17 @@ int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, float* dbias, 
 int dvae_sigmoid_bwd_f32(const float* drecon, const float* recon, float* dlogit, float* dbias, float* ws,
                          int64_t n, dvae_stream_t stream);
 
+/* ---- layout helpers.  permute3: out = in.permute(p0,p1,p2) of a contiguous [D0,D1,D2] tensor (used to
+ *      move Linear weights between the reference's NCHW flatten order, models/encoders.py:51 and
+ *      models/decoders.py:63, and the kernels' NHWC order, and sequences between batch-major and
+ *      time-major).  weighted_sum: out[0] = sum_i coefs[i] * terms[i][0] over n <= 8 device scalars
+ *      (terms: host array of device pointers, coefs: host array), the total loss of
+ *      models/disentangled_vae.py:280. */
+int dvae_permute3_f32(const float* in, float* out, int64_t D0, int64_t D1, int64_t D2, int p0, int p1,
+                      int p2, dvae_stream_t stream);
+int dvae_weighted_sum_f32(int n, const float* const* terms, const float* coefs, float* out,
+                          dvae_stream_t stream);
+
 /* ---- Linear layers (nn.Linear at models/encoders.py:43-46,87-90,197-198; models/decoders.py:30-33,
  *      91-92,102-105,218-219,228-231) as f32-MFMA GEMMs, row-major, K%4==0 / N%4==0 as noted.
  *      ws: dvae_gemm_ws_floats(M,N,K) floats (split-K slabs). */

@@ -1,0 +1,187 @@
+"""Model-level parity of the HIP path against the vectors produced by the reference itself
+(tests/golden/step_*.npz) and against the CPU oracle at the reference's full layer sizes.
+
+Tolerance contract (fp32 path): outputs, per-step loss and gradients within 1e-4 relative of the
+reference.  The reference's own fp32 gradients deviate from an fp64 run of the same code by up to a
+few 1e-4 (per-tensor relative L2), so gradients are judged against the fp64 vectors with the bar
+max(1e-4, 2 x the reference's own fp32-vs-fp64 error for that tensor).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vae_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+SETTINGS = json.load(open(os.path.join(GOLDEN, 'settings.json')))
+
+
+def load_step(kind):
+    z = np.load(os.path.join(GOLDEN, f'step_{kind}.npz'))
+    groups = {}
+    for k in z.files:
+        if '/' in k:
+            g, name = k.split('/', 1)
+            groups.setdefault(g, {})[name] = z[k]
+        else:
+            groups[k] = z[k]
+    return groups
+
+
+def build(kind, g, cfg=None):
+    import models
+    cfg = dict(SETTINGS['small'][kind]) if cfg is None else cfg
+    m = models.get_model(kind, in_channels=1, **cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in g['sd'].items()}, strict=True)
+    return m.cuda()
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def as_dict(kind, out):
+    return out if kind == 'disentangled' else dict(zip(('recon', 'z', 'mu', 'logvar'), out))
+
+
+def loss_of(kind, out, video, tcfg, beta):
+    from hipvae import losses
+    if kind == 'disentangled':
+        return losses.disentangled_loss(out, video, beta=beta, beta_content=tcfg['beta_content'],
+                                        beta_motion=tcfg['beta_motion'], recon_loss_type=tcfg['recon_loss_type'],
+                                        temporal_weight=tcfg['temporal_weight'],
+                                        independence_weight=tcfg['independence_weight'])
+    fn = losses.lstm_loss if kind == 'lstm' else losses.baseline_loss
+    recon, z, mu, logvar = out
+    return fn(recon, video, mu, logvar, beta=beta, recon_loss_type=tcfg['recon_loss_type'],
+              free_bits=tcfg['free_bits'], use_free_bits=tcfg['use_free_bits'])
+
+
+@pytest.mark.parametrize('kind', ['disentangled', 'lstm', 'baseline'])
+def test_eval_forward_matches_reference_vectors(kind):
+    g = load_step(kind)
+    m = build(kind, g).eval()
+    video = torch.from_numpy(g['video']).cuda()
+    with torch.no_grad():
+        out = m(video)
+        losses = loss_of(kind, out, video, SETTINGS['tcfg'][kind], SETTINGS['beta'])
+    for k, ref in g['eval'].items():
+        got = as_dict(kind, out)[k].cpu().numpy()
+        assert got.shape == ref.shape
+        assert rel(got, ref) < 1e-4, (k, rel(got, ref))
+    for k, ref in g['eval_loss'].items():
+        assert abs(losses[k].item() - float(ref)) <= 1e-4 * abs(float(ref)) + 1e-6, k
+    # buffers untouched in eval mode
+    for k, v in m.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            assert np.array_equal(v.cpu().numpy(), g['sd'][k]), k
+
+
+@pytest.mark.parametrize('kind', ['disentangled', 'lstm', 'baseline'])
+def test_train_step_matches_reference_vectors(kind):
+    from hipvae import rng
+    from hipvae.optim import FusedAdam
+    g = load_step(kind)
+    tcfg = SETTINGS['tcfg'][kind]
+    m = build(kind, g).train()
+    video = torch.from_numpy(g['video']).cuda()
+    eps = [torch.from_numpy(g[f'eps{k}']) for k in range(2) if f'eps{k}' in g]
+    opt = FusedAdam(m.parameters(), lr=SETTINGS['lr'], betas=(tcfg['beta1'], tcfg['beta2']),
+                    weight_decay=tcfg['weight_decay'])
+    opt.zero_grad()
+    with rng.inject_eps(eps):
+        out = m(video)
+    losses = loss_of(kind, out, video, tcfg, SETTINGS['beta'])
+    losses['total_loss'].backward()
+    for k, ref in g['train_f32'].items():
+        got = as_dict(kind, out)[k].detach().cpu().numpy()
+        assert rel(got, ref) < 1e-4, (k, rel(got, ref))
+    for k, ref in g['loss_f32'].items():
+        assert abs(losses[k].item() - float(ref)) <= 1e-4 * abs(float(ref)) + 1e-6, (k, losses[k].item(), float(ref))
+    worst = 0.0
+    for name, p in m.named_parameters():
+        g64, g32 = g['grad_f64'][name], g['grad_f32'][name]
+        assert p.grad is not None, name
+        own = rel(g32, g64)
+        err = rel(p.grad.cpu().numpy(), g64)
+        bar = max(1e-4, 2 * own)
+        assert err <= bar, (name, err, own)
+        worst = max(worst, err)
+    # clip + Adam, then every parameter and buffer against the reference's post-step state
+    total = opt.clip_grad_norm_(tcfg['gradient_clip'])
+    assert abs(total.item() - float(g['grad_norm_f32'])) <= 2e-4 * float(g['grad_norm_f32'])
+    opt.step()
+    for k, v in m.state_dict().items():
+        ref = g['post'][k]
+        if ref.dtype.kind == 'f':
+            np.testing.assert_allclose(v.cpu().numpy(), ref, rtol=2e-4, atol=5e-6, err_msg=k)
+        else:
+            assert np.array_equal(v.cpu().numpy(), ref), k
+
+
+FULL = {
+    'disentangled': dict(content_dim=128, motion_dim=128, content_channels=[32, 64, 128, 256],
+                         motion_channels=[16, 32], decoder_channels=[256, 128, 64, 32], content_feature_dim=512,
+                         motion_feature_dim=512, lstm_hidden=256, lstm_layers=1, bidirectional=True,
+                         sequence_length=20),
+    'lstm': dict(latent_dim=256, encoder_channels=[32, 64, 128, 256], decoder_channels=[256, 128, 64, 32],
+                 feature_dim=512, lstm_hidden=256, lstm_layers=2, bidirectional=True, sequence_length=20),
+    'baseline': dict(latent_dim=128, encoder_channels=[16, 32, 64, 128], decoder_channels=[128, 64, 32, 16],
+                     feature_dim=256, sequence_length=20),
+}
+
+
+@pytest.mark.parametrize('kind', ['disentangled', 'lstm', 'baseline'])
+def test_full_size_step_against_oracle(kind):
+    """The three JSON configurations at their real layer sizes, B=4: HIP path vs the fp64 oracle."""
+    import models
+    from hipvae import rng
+    B, T = 4, 20
+    torch.manual_seed(0)
+    m = models.get_model(kind, in_channels=1, **FULL[kind])
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    gen = torch.Generator().manual_seed(1)
+    video = (torch.rand(B, T, 1, 64, 64, generator=gen) > 0.9).float() * torch.rand(B, T, 1, 64, 64, generator=gen)
+    dim = FULL[kind].get('content_dim', FULL[kind].get('latent_dim'))
+    eps = [torch.randn(B, dim, generator=torch.Generator().manual_seed(100 + k)) for k in range(2)]
+    tcfg = SETTINGS['tcfg'][kind]
+    layers = FULL[kind].get('lstm_layers', 1)
+    # oracle, fp64
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    keys = O.trainable_keys(sd64)
+    leaves = {k: sd64[k].clone().requires_grad_(True) for k in keys}
+    work = dict(sd64)
+    work.update(leaves)
+    ns = {}
+    oout = O.model_forward(kind, work, video.double(), [e.double() for e in eps], True, lstm_layers=layers,
+                           new_stats=ns)
+    oloss = O.model_loss(kind, oout, video.double(), 0.4, tcfg)
+    ograds = torch.autograd.grad(oloss['total_loss'], [leaves[k] for k in keys])
+    # HIP path
+    m = m.cuda().train()
+    with rng.inject_eps(eps):
+        out = m(video.cuda())
+    losses = loss_of(kind, out, video.cuda(), tcfg, 0.4)
+    losses['total_loss'].backward()
+    for k, v in as_dict(kind, out).items():
+        r = rel(v.detach().cpu().numpy(), as_dict(kind, oout)[k].detach().numpy())
+        assert r < 1e-4, (k, r)
+    for k in ('total_loss', 'recon_loss', 'kl_loss'):
+        assert abs(losses[k].item() - oloss[k].item()) <= 1e-4 * abs(oloss[k].item()) + 1e-6, k
+    named = dict(m.named_parameters())
+    for k, og in zip(keys, ograds):
+        r = rel(named[k].grad.cpu().numpy(), og.numpy())
+        assert r < 5e-4, (k, r)          # fp32 accumulation over K up to 8192 and B*T*H*W up to 327,680 rows
+    for k, v in ns.items():
+        got = m.state_dict()[k].cpu()
+        if v.is_floating_point():
+            assert rel(got.numpy(), v.numpy()) < 1e-4, k
+        else:
+            assert int(got) == int(v), k
