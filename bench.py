@@ -1,0 +1,366 @@
+"""Training-throughput benchmark of the MI355X hot path.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = zero_grad + forward + loss + backward + (gradient all-reduce) + clip + Adam on one batch of
+synthetic 20x64x64 clips that is already resident in HBM.  Rank 0 prints ONE JSON line.  Weak
+scaling: the per-GPU batch is fixed, the global batch grows with N.
+
+Besides the headline clips/s the line carries
+  roofline      the kernel symbol that takes the most time in a step, timed live with events around
+                every launch of it on the stream it runs on: algorithmic FLOPs / time vs the fp32 MFMA peak;
+  kernels       the same for the other GEMM-shaped and HBM-bound kernel groups (short table);
+  cpu_baseline  the CPU oracle (oracle/vae_oracle.py, a restatement of the reference pinned to the
+                reference's own vectors) timed on this box's host cores on a few B=32 steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'disentangled-vae_amd'))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def load_config(name):
+    with open(os.path.join(ROOT, 'disentangled-vae_amd', 'configs', name)) as f:
+        return json.load(f)
+
+
+def model_kwargs(cfg):
+    m = cfg['model']
+    kw = dict(in_channels=m['in_channels'], sequence_length=m['sequence_length'])
+    if m['model_type'] == 'baseline':
+        kw.update(latent_dim=m['latent_dim'], encoder_channels=m['encoder_channels'],
+                  decoder_channels=m['decoder_channels'], feature_dim=m['feature_dim'])
+    elif m['model_type'] == 'lstm':
+        kw.update(latent_dim=m['latent_dim'], encoder_channels=m['encoder_channels'],
+                  decoder_channels=m['decoder_channels'], feature_dim=m['feature_dim'],
+                  lstm_hidden=m['lstm_hidden'], lstm_layers=m['lstm_layers'], bidirectional=m['bidirectional'])
+    else:
+        kw.update(content_dim=m['content_dim'], motion_dim=m['motion_dim'], content_channels=m['encoder_channels'],
+                  motion_channels=m['motion_channels'], decoder_channels=m['decoder_channels'],
+                  content_feature_dim=m['feature_dim'], motion_feature_dim=m['feature_dim'],
+                  lstm_hidden=m['lstm_hidden'], lstm_layers=m['lstm_layers'], bidirectional=m['bidirectional'],
+                  content_aggregation=m['content_aggregation'])
+    return kw
+
+
+def synthetic_clips(B, T, size, seed):
+    g = torch.Generator().manual_seed(seed)
+    u1 = torch.rand(B, T, 1, size, size, generator=g)
+    u2 = torch.rand(B, T, 1, size, size, generator=g)
+    return (u1 > 0.9).float() * u2
+
+
+def loss_call(kind, losses_mod, out, video, t, beta):
+    if kind == 'disentangled':
+        return losses_mod.disentangled_loss(out, video, beta=beta, beta_content=beta, beta_motion=beta,
+                                            recon_loss_type=t['recon_loss_type'],
+                                            temporal_weight=t['temporal_weight'],
+                                            independence_weight=t['independence_weight'])
+    fn = losses_mod.lstm_loss if kind == 'lstm' else losses_mod.baseline_loss
+    recon, z, mu, logvar = out
+    return fn(recon, video, mu, logvar, beta=beta, recon_loss_type=t['recon_loss_type'],
+              free_bits=t['free_bits'], use_free_bits=t['use_free_bits'])
+
+
+# --------------------------------------------------------------------------------------------
+# per-kernel timing: events around every launch of the GEMM-shaped and streaming entry points
+# --------------------------------------------------------------------------------------------
+class KernelTimer:
+    def __init__(self, ops):
+        self.ops = ops
+        self.records = []          # (key, start_event, end_event, work, unit)
+        self.saved = {}
+
+    def _wrap(self, name, keyfn):
+        orig = getattr(self.ops, name)
+        self.saved[name] = orig
+
+        def wrapped(*a, **k):
+            key, work, unit = keyfn(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig(*a, **k)
+            e.record()
+            self.records.append((key, s, e, work, unit))
+            return r
+        setattr(self.ops, name, wrapped)
+
+    def install(self):
+        def tile(c):
+            return 'T128' if c > 64 else ('T64' if c > 32 else 'T32')
+
+        def conv_key(x, sc, sh, act, wp, stats):
+            N, H, W, Cin = x.shape
+            Cout = wp.shape[0]
+            fl = 2.0 * N * (H // 2) * (W // 2) * Cout * 16 * Cin
+            return f"conv_fwd_kernel<{tile(Cout)},conv{',c1' if Cin == 1 else ''}>", fl, 'flop'
+
+        def deconv_key(x, sc, sh, act, wp, stats):
+            N, H, W, Cin = x.shape
+            Cout = wp.shape[1]
+            fl = 2.0 * N * 4 * H * W * Cout * 4 * Cin
+            return f"conv_fwd_kernel<{tile(Cout)},deconv>", fl, 'flop'
+
+        def wgrad_key(P, ps, ph, pa, Q, qs, qh, qa):
+            N, Hs, Ws, C1 = P.shape
+            C2 = Q.shape[3]
+            fl = 2.0 * N * Hs * Ws * C1 * 16 * C2
+            return f"conv_wgrad_kernel<C1={C1},C2={C2}>" if False else "conv_wgrad_kernel", fl, 'flop'
+
+        def gemm_key(kind):
+            def f(a, b, *rest, **kw):
+                if kind == 'nt':
+                    M, K = a.shape
+                    N = b.shape[0]
+                elif kind == 'nn':
+                    M, K = a.shape
+                    N = b.shape[1]
+                else:
+                    K, M = a.shape
+                    N = b.shape[1]
+                return f"gemm_kernel<{kind}>", 2.0 * M * N * K, 'flop'
+            return f
+
+        def final_key(x, sc, sh, act, w, b, oa):
+            return "deconv_final_kernel", float(x.numel() * 4 + x.shape[0] * 4 * x.shape[1] * x.shape[2] * 4), 'byte'
+
+        def split_key(v):
+            return "split_mean_diff_kernel", float(v.numel() * 4 * 2), 'byte'
+
+        def bn_bwd_key(du, y, *r):
+            return "bn_bwd (reduce+apply)", float(y.numel() * 4 * 5), 'byte'    # 2 reads + 2 reads + 1 write
+
+        def loss_fwd_key(recon, target, *r):
+            return "recon_loss_fwd_kernel", float(recon.numel() * 4 * 2), 'byte'
+
+        def loss_bwd_key(recon, target, *r):
+            return "recon_loss_bwd_kernel", float(recon.numel() * 4 * 3), 'byte'
+
+        def lstm_key(*a):
+            h_out = a[9]
+            B, H = h_out.shape
+            x = a[1]
+            K = H + (0 if x is None else x.shape[1])
+            return "lstm_step_fwd_kernel", 2.0 * B * 4 * H * K, 'flop'
+
+        def skinny_key(dg, w, w2, out, acc):
+            B, K = dg.shape
+            N = w.shape[1]
+            return "skinny_gemm_nn_kernel", 2.0 * B * N * K * (2 if w2 is not None else 1), 'flop'
+
+        self._wrap('conv4s2_fwd', conv_key)
+        self._wrap('deconv4s2_fwd', deconv_key)
+        self._wrap('conv4s2_wgrad', wgrad_key)
+        self._wrap('gemm_nt', gemm_key('nt'))
+        self._wrap('gemm_nn', gemm_key('nn'))
+        self._wrap('gemm_tn', gemm_key('tn'))
+        self._wrap('deconv4s2_final_fwd', final_key)
+        self._wrap('split_mean_diff', split_key)
+        self._wrap('bn_bwd', bn_bwd_key)
+        self._wrap('recon_loss_fwd', loss_fwd_key)
+        self._wrap('recon_loss_bwd', loss_bwd_key)
+        self._wrap('lstm_step_fwd', lstm_key)
+        self._wrap('skinny_gemm_nn', skinny_key)
+
+    def remove(self):
+        for n, f in self.saved.items():
+            setattr(self.ops, n, f)
+
+    def summary(self, steps):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, s, e, work, unit in self.records:
+            a = agg.setdefault(key, {'ms': 0.0, 'launches': 0, 'work': 0.0, 'unit': unit})
+            a['ms'] += s.elapsed_time(e)
+            a['launches'] += 1
+            a['work'] += work
+        rows = []
+        for key, a in agg.items():
+            sec = a['ms'] / 1e3
+            if a['unit'] == 'flop':
+                ach, peak, u, bound = a['work'] / sec / 1e12, PEAK_FP32_MFMA_TFLOPS, 'TFLOP/s', 'mfma'
+            else:
+                ach, peak, u, bound = a['work'] / sec / 1e9, PEAK_HBM_GBS, 'GB/s', 'hbm'
+            rows.append({'kernel': key, 'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': u,
+                         'frac': round(ach / peak, 4), 'ms_per_step': round(a['ms'] / steps, 4),
+                         'launches_per_step': a['launches'] // steps,
+                         'avg_launch_us': round(a['ms'] * 1e3 / a['launches'], 2)})
+        rows.sort(key=lambda r: -r['ms_per_step'])
+        return rows
+
+
+# --------------------------------------------------------------------------------------------
+def cpu_baseline(kind, cfg, steps=3, batch=32):
+    """The CPU oracle's training step timed on the host cores (bounded sample)."""
+    from oracle import vae_oracle as O
+    import models
+    torch.manual_seed(0)
+    kw = model_kwargs(cfg)
+    # weights with the reference's default initialisation; parameter containers only, no HIP compute
+    m = models.get_model(kind, **kw)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    T, size = cfg['data']['sequence_length'], cfg['data']['frame_size']
+    video = synthetic_clips(batch, T, size, 0)
+    dim = kw.get('content_dim', kw.get('latent_dim'))
+    eps = [torch.randn(batch, dim, generator=torch.Generator().manual_seed(100 + k)) for k in range(2)]
+    t = dict(cfg['training'])
+    t['beta_content'] = t['beta_motion'] = 4.0
+    layers = kw.get('lstm_layers', 1)
+    opt = {}
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        sd, opt, _, _ = O.train_step(kind, sd, opt, video, eps, 4.0, t, t['learning_rate'], lstm_layers=layers,
+                                     bidirectional=kw.get('bidirectional', True))
+        times.append(time.perf_counter() - t0)
+    med = sorted(times[1:])[len(times[1:]) // 2]
+    return {'value': round(batch / med, 2), 'unit': 'clips/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{steps} training steps (after 1 warm-up) of the CPU oracle, batch {batch}, fp32, '
+                      f'median {med * 1e3:.0f} ms/step'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default='disentangled_simple.json')
+    ap.add_argument('--batch', type=int, default=256, help='clips per GPU')
+    ap.add_argument('--mode', default='train', choices=['train', 'infer'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-table', action='store_true')
+    ap.add_argument('--bucket-mb', type=float, default=16.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    import models
+    from hipvae import losses as L, ops
+    from hipvae.optim import FusedAdam
+    from hipvae.parallel import GradSync
+
+    cfg = load_config(args.config)
+    kind = cfg['model']['model_type']
+    t = cfg['training']
+    T, size = cfg['data']['sequence_length'], cfg['data']['frame_size']
+    B = args.batch
+    torch.manual_seed(0)
+    model = models.get_model(kind, **model_kwargs(cfg)).to(dev)
+    n_params = sum(p.numel() for p in model.parameters())
+    opt = FusedAdam(model.parameters(), lr=t['learning_rate'], betas=(t['beta1'], t['beta2']),
+                    weight_decay=t['weight_decay'])
+    sync = GradSync(model, bucket_mb=args.bucket_mb) if world > 1 else None
+    ring = [synthetic_clips(B, T, size, 1000 * rank + i).to(dev) for i in range(4)]
+    beta = 4.0
+
+    def train_step(i):
+        video = ring[i % len(ring)]
+        if sync is not None:
+            sync.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+        out = model(video)
+        losses = loss_call(kind, L, out, video, t, beta)
+        losses['total_loss'].backward()
+        if sync is not None:
+            sync.finish()
+        if t['gradient_clip'] > 0:
+            opt.clip_grad_norm_(t['gradient_clip'], fold_into_step=True)
+        opt.step()
+        return losses
+
+    def infer_step(i):
+        with torch.no_grad():
+            return model(ring[i % len(ring)])
+
+    if args.mode == 'train':
+        model.train()
+        step = train_step
+    else:
+        model.eval()
+        step = infer_step
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    value = world * B * args.steps / elapsed
+
+    result = {
+        'metric': ('training' if args.mode == 'train' else 'inference') +
+                  ' clips/sec (20x64x64 Moving MNIST) at 1/2/4/8 MI355X vs host CPU',
+        'value': round(value, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f"{cfg['name']} ({args.config}) {args.mode} step, beta=4, {T}x{size}x{size} clips, "
+                               f"batch {B}/GPU, fp32 MFMA", 'global_batch': B * world, 'params': n_params,
+                   'parallelism': f'dp{world}'},
+    }
+    if args.mode == 'train':
+        result['loss'] = round(float(last['total_loss'].item()), 3)
+
+    if rank == 0 and world == 1 and not args.no_kernel_table:
+        kt = KernelTimer(ops)
+        kt.install()
+        nprof = 3
+        for i in range(nprof):
+            step(i)
+        rows = kt.summary(nprof)
+        kt.remove()
+        top = rows[0]
+        result['roofline'] = {'kernel': top['kernel'], 'bound': top['bound'], 'achieved': top['achieved'],
+                              'peak': top['peak'], 'unit': top['unit'], 'frac': top['frac'], 'traffic': None,
+                              'avg_launch_us': top['avg_launch_us'], 'launches_per_step': top['launches_per_step'],
+                              'ms_per_step': top['ms_per_step']}
+        result['kernels'] = [{k: r[k] for k in ('kernel', 'bound', 'achieved', 'unit', 'frac', 'ms_per_step')}
+                             for r in rows[:12]]
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == 'train':
+        result['cpu_baseline'] = cpu_baseline(kind, cfg)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
