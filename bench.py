@@ -118,7 +118,11 @@ class KernelTimer:
             N, Hs, Ws, C1 = P.shape
             C2 = Q.shape[3]
             fl = 2.0 * N * Hs * Ws * C1 * 16 * C2
-            return f"conv_wgrad_kernel<C1={C1},C2={C2}>" if False else "conv_wgrad_kernel", fl, 'flop'
+            if C2 == 1:
+                var = 'T128x32,c1'
+            else:
+                var = 'T32x128' if C1 <= 32 else ('T64x128' if C1 <= 64 else 'T128x128')
+            return f"conv_wgrad_kernel<{var}>", fl, 'flop'
 
         def gemm_key(kind):
             def f(a, b, *rest, **kw):

@@ -6,6 +6,10 @@ import ctypes
 import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
 
+# torch must be imported first: it brings its own HIP runtime (libamdhip64), and the kernels have to
+# run on that same runtime instance to share torch's device context, streams and allocations.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libdvae_hip.so')
 
