@@ -15,6 +15,19 @@ Tensor = torch.Tensor
 _KIND = {'mse': 0, 'bce': 1}
 
 
+class LossDict(dict):
+    """The reference's loss dictionary (name -> 0-dim tensor).  Every device entry is a view of one
+    packed tensor, exposed as `.packed` with `.layout` (name -> index), so a caller can accumulate a
+    whole step's values with one device add and read them back once per logging interval instead of
+    calling .item() per entry per step."""
+
+    def __init__(self, packed: Tensor, layout: Dict[str, int], beta: float):
+        super().__init__({k: packed[i] for k, i in layout.items()})
+        self['beta'] = torch.tensor(beta)          # a CPU tensor, as in the reference
+        self.packed = packed
+        self.layout = layout
+
+
 def _kind(name: str) -> int:
     if name not in _KIND:
         raise ValueError(f"Unknown recon_loss_type: {name}")
@@ -72,9 +85,8 @@ def disentangled_loss(output: Dict[str, Tensor], target: Tensor, beta: float = 1
                                 output['mu_motion'], output['logvar_motion'], output['z_content'],
                                 output['z_motion'], float(bc), float(bm), kind, float(temporal_weight),
                                 float(independence_weight))
-    return {'total_loss': v[0], 'recon_loss': v[3], 'recon_loss_per_pixel': v[2], 'kl_loss': v[1],
-            'kl_content': v[5], 'kl_motion': v[8], 'temporal_loss': v[4], 'independence_loss': v[11],
-            'beta': torch.tensor(beta)}
+    return LossDict(v, {'total_loss': 0, 'recon_loss': 3, 'recon_loss_per_pixel': 2, 'kl_loss': 1,
+                        'kl_content': 5, 'kl_motion': 8, 'temporal_loss': 4, 'independence_loss': 11}, beta)
 
 
 class _TupleLoss(torch.autograd.Function):
@@ -113,13 +125,13 @@ def lstm_loss(recon, target, mu, logvar, beta: float = 1.0, recon_loss_type: str
               temporal_weight: float = 0.0, free_bits: float = 0.0, use_free_bits: bool = False):
     """Same signature and keys as models/lstm_vae.py:167-220."""
     v = _tuple_loss(recon, target, mu, logvar, beta, recon_loss_type, temporal_weight, free_bits, use_free_bits)
-    return {'total_loss': v[0], 'recon_loss': v[2], 'recon_loss_per_pixel': v[1], 'kl_loss': v[4],
-            'kl_loss_raw': v[5], 'kl_per_dim': v[6], 'temporal_loss': v[3], 'beta': torch.tensor(beta)}
+    return LossDict(v, {'total_loss': 0, 'recon_loss': 2, 'recon_loss_per_pixel': 1, 'kl_loss': 4,
+                        'kl_loss_raw': 5, 'kl_per_dim': 6, 'temporal_loss': 3}, beta)
 
 
 def baseline_loss(recon, target, mu, logvar, beta: float = 1.0, recon_loss_type: str = 'mse',
                   free_bits: float = 0.0, use_free_bits: bool = False):
     """Same signature and keys as models/baseline_vae.py:208-252."""
     v = _tuple_loss(recon, target, mu, logvar, beta, recon_loss_type, 0.0, free_bits, use_free_bits)
-    return {'total_loss': v[0], 'recon_loss': v[2], 'recon_loss_per_pixel': v[1], 'kl_loss': v[4],
-            'kl_loss_raw': v[5], 'kl_per_dim': v[6], 'beta': torch.tensor(beta)}
+    return LossDict(v, {'total_loss': 0, 'recon_loss': 2, 'recon_loss_per_pixel': 1, 'kl_loss': 4,
+                        'kl_loss_raw': 5, 'kl_per_dim': 6}, beta)

@@ -1,0 +1,111 @@
+"""Command-line entry point: `python -m training.train --config configs/<file>.json --device cuda`
+(flags as in the reference, training/train.py:32-101).  Launched under torch.distributed.run it trains
+data-parallel, one process per GPU."""
+import argparse
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from training.config import ExperimentConfig, get_baseline_config, get_disentangled_config, get_lstm_config
+
+
+def set_seed(seed: int):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description='Train Video VAE models (MI355X build)')
+    p.add_argument('--config', type=str, default=None, help='JSON config file (overrides the other flags)')
+    p.add_argument('--model', type=str, default='disentangled', choices=['baseline', 'lstm', 'disentangled'])
+    p.add_argument('--name', type=str, default=None)
+    p.add_argument('--train-size', type=int, default=10000)
+    p.add_argument('--val-size', type=int, default=1000)
+    p.add_argument('--batch-size', type=int, default=32)
+    p.add_argument('--num-workers', type=int, default=4)
+    p.add_argument('--latent-dim', type=int, default=256)
+    p.add_argument('--content-dim', type=int, default=128)
+    p.add_argument('--motion-dim', type=int, default=128)
+    p.add_argument('--lstm-hidden', type=int, default=256)
+    p.add_argument('--epochs', type=int, default=100)
+    p.add_argument('--lr', type=float, default=1e-4)
+    p.add_argument('--beta', type=float, default=4.0)
+    p.add_argument('--warmup', type=int, default=10)
+    p.add_argument('--no-kl-annealing', action='store_true')
+    p.add_argument('--independence-weight', type=float, default=0.1)
+    p.add_argument('--content-agg', type=str, default='mean', choices=['mean', 'middle'])
+    p.add_argument('--device', type=str, default='mps', choices=['mps', 'cuda', 'cpu'])
+    p.add_argument('--seed', type=int, default=42)
+    p.add_argument('--resume', action='store_true')
+    p.add_argument('--save-every', type=int, default=10)
+    p.add_argument('--visualize-every', type=int, default=5)
+    return p.parse_args(argv)
+
+
+def config_from_args(args) -> ExperimentConfig:
+    if args.config is not None:
+        print(f"Loading config from: {args.config}")
+        cfg = ExperimentConfig.load(args.config)
+        if args.device:                      # always true: the flag wins over the file (reference :113-114)
+            cfg.training.device = args.device
+        return cfg
+    cfg = {'baseline': get_baseline_config, 'lstm': get_lstm_config}.get(args.model, get_disentangled_config)()
+    cfg.name = args.name if args.name is not None else f"{args.model}_vae"
+    d, m, t = cfg.data, cfg.model, cfg.training
+    d.train_size, d.val_size, d.batch_size, d.num_workers, d.seed = (args.train_size, args.val_size, args.batch_size,
+                                                                     args.num_workers, args.seed)
+    m.latent_dim, m.content_dim, m.motion_dim, m.lstm_hidden = (args.latent_dim, args.content_dim, args.motion_dim,
+                                                                args.lstm_hidden)
+    m.content_aggregation = args.content_agg
+    t.num_epochs, t.learning_rate, t.beta_vae, t.warmup_epochs = args.epochs, args.lr, args.beta, args.warmup
+    t.use_kl_annealing = not args.no_kl_annealing
+    t.independence_weight = args.independence_weight
+    t.device = args.device
+    t.save_every, t.visualize_every = args.save_every, args.visualize_every
+    return cfg
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    cfg = config_from_args(args)
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    if world > 1:
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+        dist.init_process_group('nccl')
+    set_seed(cfg.data.seed)
+    if rank == 0:
+        print(f"Model type: {cfg.model.model_type}")
+        print(f"Data: train {cfg.data.train_size}, val {cfg.data.val_size}, batch {cfg.data.batch_size}"
+              f"{f' per GPU x {world}' if world > 1 else ''}")
+        print(f"Training: {cfg.training.num_epochs} epochs, lr {cfg.training.learning_rate}, "
+              f"beta {cfg.training.beta_vae}, KL annealing {cfg.training.use_kl_annealing}, "
+              f"device {cfg.training.device}")
+    from data import get_moving_mnist_dataloaders
+    from training.trainer import create_trainer
+    train_loader, val_loader, _ = get_moving_mnist_dataloaders(
+        root=cfg.data.root, batch_size=cfg.data.batch_size, train_size=cfg.data.train_size,
+        val_size=cfg.data.val_size, test_size=cfg.data.test_size, sequence_length=cfg.data.sequence_length,
+        frame_size=cfg.data.frame_size, num_digits=cfg.data.num_digits, num_workers=cfg.data.num_workers,
+        seed=cfg.data.seed, rank=rank, world_size=world)
+    trainer = create_trainer(cfg, train_loader, val_loader)
+    history = trainer.train(resume=args.resume)
+    if rank == 0:
+        print(f"Results saved to: {trainer.results_dir}")
+        print(f"Checkpoints saved to: {trainer.checkpoint_dir}")
+    if world > 1:
+        dist.destroy_process_group()
+    return history
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,362 @@
+"""Trainer with the reference's surface (training/trainer.py:26-474): same constructor, epoch loop,
+beta schedule, loss dispatch, clip + Adam step, LR schedule rule, history, TensorBoard tags and
+checkpoint layout, driving the MI355X kernels.
+
+What differs underneath:
+  * forward, loss, backward, gradient norm/clip and Adam are HIP kernels (hipvae.*); there is no CPU
+    path, so a configuration that does not resolve to a GPU is an error instead of a silent fallback;
+  * loss values stay on the device during an epoch: one packed add per step, one read-back per
+    logging interval / epoch, instead of >= 9 .item() synchronisations per step;
+  * with torch.distributed initialised (one process per GPU) gradients are averaged across ranks by
+    bucketed all-reduce overlapped with backward (hipvae.parallel.GradSync); rank 0 logs and saves.
+"""
+import json
+import math
+import os
+import sys
+import time
+from typing import Dict, Optional, Tuple
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.optim as optim
+
+from hipvae.losses import baseline_loss, disentangled_loss, lstm_loss
+from hipvae.optim import FusedAdam
+from training.config import ExperimentConfig
+
+try:
+    from torch.utils.tensorboard import SummaryWriter
+except Exception:                                       # tensorboard is optional: logging only
+    class SummaryWriter:                                # type: ignore
+        def __init__(self, *a, **k): pass
+        def add_scalar(self, *a, **k): pass
+        def add_image(self, *a, **k): pass
+        def close(self): pass
+
+try:
+    from tqdm import tqdm
+except Exception:
+    def tqdm(it, **k):                                  # type: ignore
+        return it
+
+
+def beta_for_epoch(t, epoch: int) -> float:
+    """KL weight schedule, per epoch (reference: Trainer._get_beta, training/trainer.py:115-149)."""
+    if epoch < t.kl_start_epoch:
+        return 0.0
+    if not t.use_kl_annealing or t.warmup_epochs <= 0:
+        return t.beta_vae
+    since = epoch - t.kl_start_epoch
+    if t.annealing_type == 'linear':
+        return t.beta_vae * (since / t.warmup_epochs) if since < t.warmup_epochs else t.beta_vae
+    if t.annealing_type == 'cosine':
+        if since >= t.warmup_epochs:
+            return t.beta_vae
+        return t.beta_vae * (1 - math.cos(since / t.warmup_epochs * math.pi)) / 2
+    if t.annealing_type == 'cyclical':
+        pos = since % t.warmup_epochs
+        return t.beta_vae * 0.5 * (1 - math.cos(pos / t.warmup_epochs * math.pi))
+    return t.beta_vae
+
+
+class Trainer:
+
+    def __init__(self, model: nn.Module, config: ExperimentConfig, train_loader, val_loader,
+                 device: Optional[torch.device] = None):
+        self.config = config
+        self.train_loader = train_loader
+        self.val_loader = val_loader
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.rank = dist.get_rank() if self.distributed else 0
+        if device is None:
+            if config.training.device == 'cuda' and torch.cuda.is_available():
+                device = torch.device('cuda', torch.cuda.current_device())
+            else:
+                raise RuntimeError(
+                    f"training.device={config.training.device!r} does not resolve to a GPU here "
+                    f"(torch.cuda.is_available()={torch.cuda.is_available()}). This build runs on MI355X "
+                    "only and has no CPU fallback: launch with --device cuda on a ROCm machine.")
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError("this build has no CPU path; pass a cuda device")
+        if self.rank == 0:
+            print(f"Training on device: {self.device}")
+        self.model = model.to(self.device)
+        self.model_type = getattr(model, 'model_type', 'unknown')
+
+        t = config.training
+        self.optimizer = FusedAdam(self.model.parameters(), lr=t.learning_rate, betas=(t.beta1, t.beta2),
+                                   weight_decay=t.weight_decay)
+        self.scheduler = self._setup_scheduler()
+        self.loss_fn = self._get_loss_fn()
+        self.grad_sync = None
+        if self.distributed:
+            from hipvae.parallel import GradSync
+            self.grad_sync = GradSync(self.model)
+
+        self.checkpoint_dir = os.path.join(t.checkpoint_dir, config.name)
+        self.results_dir = os.path.join(t.results_dir, config.name)
+        if self.rank == 0:
+            for d in (self.checkpoint_dir, self.results_dir, os.path.join(self.results_dir, 'figures'),
+                      os.path.join(self.results_dir, 'videos')):
+                os.makedirs(d, exist_ok=True)
+            config.save(os.path.join(self.checkpoint_dir, 'config.json'))
+            self.writer = SummaryWriter(os.path.join(self.results_dir, 'logs'))
+        else:
+            self.writer = None
+
+        self.current_epoch = 0
+        self.global_step = 0
+        self.best_val_loss = float('inf')
+        self.history = {k: [] for k in ('train_loss', 'val_loss', 'train_recon', 'val_recon', 'train_kl',
+                                        'val_kl', 'learning_rate')}
+
+    # ------------------------------------------------------------------ set-up helpers
+    def _setup_scheduler(self):
+        t = self.config.training
+        if t.lr_scheduler == 'exponential':
+            return optim.lr_scheduler.ExponentialLR(self.optimizer, gamma=t.lr_decay)
+        if t.lr_scheduler == 'cosine':
+            return optim.lr_scheduler.CosineAnnealingLR(self.optimizer, T_max=t.num_epochs, eta_min=t.lr_min)
+        return None
+
+    def _get_loss_fn(self):
+        return {'baseline_vae': baseline_loss, 'lstm_vae': lstm_loss,
+                'disentangled_vae': disentangled_loss}.get(self.model_type, baseline_loss)
+
+    def _get_beta(self, epoch: int) -> float:
+        return beta_for_epoch(self.config.training, epoch)
+
+    def _compute_loss(self, video: torch.Tensor, beta: float) -> Tuple[Dict[str, torch.Tensor], torch.Tensor]:
+        t = self.config.training
+        if self.model_type == 'disentangled_vae':
+            output = self.model(video)
+            losses = self.loss_fn(output, video, beta=beta, beta_content=t.beta_content, beta_motion=t.beta_motion,
+                                  recon_loss_type=t.recon_loss_type, temporal_weight=t.temporal_weight,
+                                  independence_weight=t.independence_weight)
+            return losses, output['recon']
+        recon, z, mu, logvar = self.model(video)
+        # temporal_weight is not forwarded on this path (the reference does not either, :171-177)
+        losses = self.loss_fn(recon, video, mu, logvar, beta=beta, recon_loss_type=t.recon_loss_type,
+                              free_bits=t.free_bits, use_free_bits=t.use_free_bits)
+        return losses, recon
+
+    # ------------------------------------------------------------------ one optimisation step
+    def train_step(self, video: torch.Tensor, beta: float):
+        """zero_grad, forward, loss, backward, (all-reduce), clip, Adam (training/trainer.py:192-204)."""
+        if self.grad_sync is not None:
+            self.grad_sync.zero_grad()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+        losses, _ = self._compute_loss(video, beta)
+        losses['total_loss'].backward()
+        if self.grad_sync is not None:
+            self.grad_sync.finish()
+        if self.config.training.gradient_clip > 0:
+            # the clip coefficient is folded into Adam's gradient read: one pass less over the gradients
+            self.optimizer.clip_grad_norm_(self.config.training.gradient_clip, fold_into_step=True)
+        self.optimizer.step()
+        return losses
+
+    @staticmethod
+    def _unpack(losses, packed_cpu) -> Dict[str, float]:
+        out = {k: float(packed_cpu[i]) for k, i in losses.layout.items()}
+        out['beta'] = float(losses['beta'])
+        return out
+
+    def train_epoch(self) -> Dict[str, float]:
+        self.model.train()
+        beta = self._get_beta(self.current_epoch)
+        t = self.config.training
+        acc = None
+        last = None
+        n = 0
+        bar = tqdm(self.train_loader, desc=f'Epoch {self.current_epoch}', dynamic_ncols=True, leave=True,
+                   mininterval=0.5, disable=self.rank != 0) if self.rank == 0 else self.train_loader
+        for video, _meta in bar:
+            video = video.to(self.device, non_blocking=True)
+            last = self.train_step(video, beta)
+            packed = last.packed.detach()
+            acc = packed.clone() if acc is None else acc.add_(packed)
+            n += 1
+            if self.rank == 0 and self.global_step % t.log_every == 0:
+                cur = self._unpack(last, packed.cpu())                 # the only per-step synchronisation
+                for k, v in cur.items():
+                    self.writer.add_scalar(f'train/{k}', v, self.global_step)
+                self.writer.add_scalar('train/beta', beta, self.global_step)
+                self.writer.add_scalar('train/lr', self.optimizer.param_groups[0]['lr'], self.global_step)
+                if hasattr(bar, 'set_postfix'):
+                    post = {'loss': f"{cur['total_loss']:.4f}", 'recon': f"{cur['recon_loss']:.4f}",
+                            'kl': f"{cur['kl_loss']:.4f}", 'β': f'{beta:.3f}'}
+                    if 'recon_loss_per_pixel' in cur:
+                        post['pix'] = f"{cur['recon_loss_per_pixel']:.6f}"
+                    if 'kl_loss_raw' in cur:
+                        post['kl_raw'] = f"{cur['kl_loss_raw']:.4f}"
+                    bar.set_postfix(post, refresh=False)
+            self.global_step += 1
+        if n == 0:
+            return {}
+        out = self._unpack(last, (acc / n).cpu())
+        out['beta'] = beta
+        return out
+
+    @torch.no_grad()
+    def validate(self) -> Dict[str, float]:
+        self.model.eval()
+        beta = self.config.training.beta_vae          # the final beta, not the annealed one (reference :243)
+        acc, last, n = None, None, 0
+        for video, _meta in self.val_loader:
+            video = video.to(self.device, non_blocking=True)
+            last, _ = self._compute_loss(video, beta)
+            acc = last.packed.clone() if acc is None else acc.add_(last.packed)
+            n += 1
+        if n == 0:
+            return {}
+        out = self._unpack(last, (acc / n).cpu())
+        out['beta'] = beta
+        return out
+
+    # ------------------------------------------------------------------ checkpoints
+    def save_checkpoint(self, filename: str = 'checkpoint.pt'):
+        if self.rank != 0:
+            return
+        ckpt = {
+            'epoch': self.current_epoch,
+            'global_step': self.global_step,
+            'model_state_dict': self.model.state_dict(),
+            'optimizer_state_dict': self.optimizer.state_dict(),
+            'best_val_loss': self.best_val_loss,
+            'history': self.history,
+            'config': self.config.to_dict(),
+        }
+        if self.scheduler is not None:
+            ckpt['scheduler_state_dict'] = self.scheduler.state_dict()
+        path = os.path.join(self.checkpoint_dir, filename)
+        torch.save(ckpt, path)
+        print(f"Saved checkpoint to {path}")
+
+    def load_checkpoint(self, filename: str = 'checkpoint.pt'):
+        path = os.path.join(self.checkpoint_dir, filename)
+        if not os.path.exists(path):
+            print(f"No checkpoint found at {path}")
+            return False
+        ckpt = torch.load(path, map_location=self.device, weights_only=False)
+        self.model.load_state_dict(ckpt['model_state_dict'])
+        self.optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+        self.current_epoch = ckpt['epoch']            # resumes AT the saved epoch, as the reference does
+        self.global_step = ckpt['global_step']
+        self.best_val_loss = ckpt['best_val_loss']
+        self.history = ckpt['history']
+        if self.scheduler is not None and 'scheduler_state_dict' in ckpt:
+            self.scheduler.load_state_dict(ckpt['scheduler_state_dict'])
+        print(f"Loaded checkpoint from {path} (epoch {self.current_epoch})")
+        return True
+
+    # ------------------------------------------------------------------ TensorBoard images
+    @torch.no_grad()
+    def visualize_reconstructions(self, num_samples: int = 4):
+        if self.rank != 0:
+            return
+        self.model.eval()
+        video, _ = next(iter(self.val_loader))
+        video = video[:num_samples].to(self.device)
+        out = self.model(video)
+        recon = out['recon'] if self.model_type == 'disentangled_vae' else out[0]
+        for i in range(min(num_samples, video.size(0))):
+            for tag, src in (('original', video), ('reconstructed', recon)):
+                self.writer.add_image(f'recon/{tag}_{i}_first', src[i, 0], self.current_epoch)
+                self.writer.add_image(f'recon/{tag}_{i}_last', src[i, -1], self.current_epoch)
+
+    @torch.no_grad()
+    def visualize_samples(self, num_samples: int = 4):
+        if self.rank != 0:
+            return
+        self.model.eval()
+        samples = self.model.sample(num_samples=num_samples, device=self.device)
+        for i in range(samples.size(0)):
+            self.writer.add_image(f'samples/sample_{i}_first', samples[i, 0], self.current_epoch)
+            self.writer.add_image(f'samples/sample_{i}_last', samples[i, -1], self.current_epoch)
+
+    # ------------------------------------------------------------------ the epoch driver
+    def train(self, resume: bool = False):
+        if resume:
+            self.load_checkpoint()                    # looks for 'checkpoint.pt', like the reference
+        t = self.config.training
+        start_epoch = self.current_epoch
+        if self.rank == 0:
+            print(f"\nStarting training from epoch {start_epoch}")
+            print(f"Model type: {self.model_type}")
+            print(f"Device: {self.device}")
+            print(f"Number of parameters: {sum(p.numel() for p in self.model.parameters()):,}\n")
+        t0 = time.time()
+        for epoch in range(start_epoch, t.num_epochs):
+            self.current_epoch = epoch
+            tr = self.train_epoch()
+            va = self.validate()
+            if self.scheduler is not None and self.optimizer.param_groups[0]['lr'] > t.lr_min:
+                self.scheduler.step()                 # stops once lr <= lr_min (reference :373-375)
+            lr = self.optimizer.param_groups[0]['lr']
+            for key, src, name in (('train_loss', tr, 'total_loss'), ('val_loss', va, 'total_loss'),
+                                   ('train_recon', tr, 'recon_loss'), ('val_recon', va, 'recon_loss'),
+                                   ('train_kl', tr, 'kl_loss'), ('val_kl', va, 'kl_loss')):
+                self.history[key].append(src[name])
+            self.history['learning_rate'].append(lr)
+            if self.rank == 0:
+                self.writer.add_scalar('epoch/train_loss', tr['total_loss'], epoch)
+                self.writer.add_scalar('epoch/val_loss', va['total_loss'], epoch)
+                self.writer.add_scalar('epoch/learning_rate', lr, epoch)
+                print(f"\nEpoch {epoch}:")
+                for label, d in (('Train', tr), ('Val  ', va)):
+                    pix = d.get('recon_loss_per_pixel', d['recon_loss'])
+                    print(f"  {label} - Total: {d['total_loss']:.2f}, Recon: {d['recon_loss']:.2f} "
+                          f"(pix: {pix:.6f}), KL: {d['kl_loss']:.2f}")
+                print(f"  LR: {lr:.6f}, β: {self._get_beta(epoch):.3f}")
+            if va['total_loss'] < self.best_val_loss:
+                self.best_val_loss = va['total_loss']
+                self.save_checkpoint('best_model.pt')
+                if self.rank == 0:
+                    print(f"  New best model! Val loss: {self.best_val_loss:.4f}")
+            if (epoch + 1) % t.save_every == 0:
+                self.save_checkpoint(f'checkpoint_epoch_{epoch}.pt')
+            if (epoch + 1) % t.visualize_every == 0:
+                self.visualize_reconstructions()
+                self.visualize_samples()
+        self.save_checkpoint('final_model.pt')
+        if self.rank == 0:
+            with open(os.path.join(self.results_dir, 'training_history.json'), 'w') as f:
+                json.dump(self.history, f, indent=2)
+            print(f"\nTraining completed in {(time.time() - t0) / 60:.1f} minutes")
+            print(f"Best validation loss: {self.best_val_loss:.4f}")
+            self.writer.close()
+        return self.history
+
+
+def model_kwargs_from_config(config: ExperimentConfig) -> Dict:
+    """Config -> constructor arguments (reference: create_trainer, training/trainer.py:435-470;
+    note content_channels <- encoder_channels and both feature dims <- feature_dim)."""
+    m = config.model
+    kw = {'in_channels': m.in_channels, 'sequence_length': m.sequence_length}
+    if m.model_type == 'baseline':
+        kw.update(latent_dim=m.latent_dim, encoder_channels=m.encoder_channels,
+                  decoder_channels=m.decoder_channels, feature_dim=m.feature_dim)
+    elif m.model_type == 'lstm':
+        kw.update(latent_dim=m.latent_dim, encoder_channels=m.encoder_channels,
+                  decoder_channels=m.decoder_channels, feature_dim=m.feature_dim, lstm_hidden=m.lstm_hidden,
+                  lstm_layers=m.lstm_layers, bidirectional=m.bidirectional)
+    elif m.model_type == 'disentangled':
+        kw.update(content_dim=m.content_dim, motion_dim=m.motion_dim, content_channels=m.encoder_channels,
+                  motion_channels=m.motion_channels, decoder_channels=m.decoder_channels,
+                  content_feature_dim=m.feature_dim, motion_feature_dim=m.feature_dim, lstm_hidden=m.lstm_hidden,
+                  lstm_layers=m.lstm_layers, bidirectional=m.bidirectional,
+                  content_aggregation=m.content_aggregation)
+    return kw
+
+
+def create_trainer(config: ExperimentConfig, train_loader, val_loader) -> Trainer:
+    from models import get_model
+    model = get_model(config.model.model_type, **model_kwargs_from_config(config))
+    return Trainer(model, config, train_loader, val_loader)
