@@ -165,7 +165,11 @@ struct ConvALoader {
 template <class T, int MODE, bool C1>
 __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * T::STAGE_FLOATS];
-  const int phase = blockIdx.z, ph = phase >> 1, pw = phase & 1;
+  // transposed conv: the four sub-pixel phases of one M tile sit in adjacent workgroups, so the input
+  // tile they share is fetched from HBM once and re-read through L2
+  const int phase = MODE == 1 ? (int)(blockIdx.x & 3) : 0, ph = phase >> 1, pw = phase & 1;
+  const int bx = MODE == 1 ? (int)(blockIdx.x >> 2) : (int)blockIdx.x;
+  const int gx = MODE == 1 ? (int)(gridDim.x >> 2) : (int)gridDim.x;
   const int64_t n0 = (int64_t)blockIdx.y * T::BN;
   const int ktiles = (g.K + 31) / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -179,7 +183,7 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs g) {
 #pragma unroll
   for (int j = 0; j < T::TN; ++j) s1[j] = s2[j] = 0.f;
 
-  for (int mt = blockIdx.x; mt < g.mtiles; mt += gridDim.x) {
+  for (int mt = bx; mt < g.mtiles; mt += gx) {
     const int64_t m0 = (int64_t)mt * T::BM;
     la.set_tile(m0);
     f32x16 acc[T::TM][T::TN];
@@ -241,7 +245,7 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs g) {
       }
       const int64_t n = n0 + col;
       if (n < g.Cout) {
-        const int64_t part = (int64_t)phase * gridDim.x + blockIdx.x;
+        const int64_t part = (int64_t)phase * gx + bx;
         g.stats[(part * 2 + 0) * g.Cout + n] = a;
         g.stats[(part * 2 + 1) * g.Cout + n] = b;
       }
@@ -262,7 +266,7 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   {                                                                                                  \
     g.mtiles = (int)ceil_div64(g.M, TILE::BM);                                                       \
     int gx = g.mtiles < CONV_MAX_PARTS ? g.mtiles : CONV_MAX_PARTS;                                  \
-    dim3 grid(gx, (unsigned)ceil_div64(g.Cout, TILE::BN), phases);                                   \
+    dim3 grid(gx * phases, (unsigned)ceil_div64(g.Cout, TILE::BN), 1);                               \
     hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG>), grid, dim3(256), 0, stream, g);        \
   }
   typedef Tile<128, 128, 2, 2, true, true> T128;
@@ -348,65 +352,87 @@ struct WgradArgs {
   int ktiles_per_split;
 };
 
+// Both operands of the weight-gradient GEMM are row-contiguous tiles whose column position is
+// fixed per thread for the whole K loop (256 % (R/4) == 0), so everything that depends on the column
+// (channel, filter tap, pixel offset) is computed once; per fetch only the pixel index m moves.
 template <int V4, int R>
 struct WgradPLoader {
   const WgradArgs& g;
-  int64_t c0;
+  int64_t c;      // channel of this thread's 4-float chunk
+  int kr0;
+  bool col_ok;
+  float4 sc, sh;
+  __device__ __forceinline__ WgradPLoader(const WgradArgs& g_, int64_t c0) : g(g_) {
+    c = c0 + 4 * (threadIdx.x % (R / 4));
+    kr0 = threadIdx.x / (R / 4);
+    col_ok = c < g.C1;
+    sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col_ok && g.p_scale) {
+      sc = *reinterpret_cast<const float4*>(g.p_scale + c);
+      sh = *reinterpret_cast<const float4*>(g.p_shift + c);
+    }
+  }
   __device__ __forceinline__ void fetch(int kt, float4 (&r)[V4]) const {
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      int kr, c4;
-      rc_pos<R>(v, kr, c4);
-      const int64_t m = (int64_t)kt * 32 + kr;
-      const int64_t c = c0 + 4 * c4;
+      const int64_t m = (int64_t)kt * 32 + kr0 + v * (1024 / R);
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < g.Mtot && c < g.C1) {
+      if (col_ok && m < g.Mtot) {
         val = *reinterpret_cast<const float4*>(g.P + m * g.C1 + c);
-        val = affine_act4(val, g.p_scale, g.p_shift, (int)c, g.p_act);
+        if (g.p_scale) {
+          val.x = fmaf(val.x, sc.x, sh.x); val.y = fmaf(val.y, sc.y, sh.y);
+          val.z = fmaf(val.z, sc.z, sh.z); val.w = fmaf(val.w, sc.w, sh.w);
+        }
+        if (g.p_act == DVAE_ACT_LRELU) {
+          val.x = lrelu(val.x); val.y = lrelu(val.y); val.z = lrelu(val.z); val.w = lrelu(val.w);
+        }
       }
       r[v] = val;
     }
   }
 };
 
-template <int V4, int R, bool C1>
+template <int V4, int R>
 struct WgradQLoader {
   const WgradArgs& g;
-  int64_t n0;
+  int c2, dh, dw, kr0;
+  bool col_ok;
+  float4 sc, sh;
+  __device__ __forceinline__ WgradQLoader(const WgradArgs& g_, int64_t n0) : g(g_) {
+    const int64_t col = n0 + 4 * (threadIdx.x % (R / 4));
+    kr0 = threadIdx.x / (R / 4);
+    col_ok = col < g.NC;
+    const int tap = (int)(col / g.C2);
+    c2 = (int)(col - (int64_t)tap * g.C2);
+    dh = (tap >> 2) - 1;
+    dw = (tap & 3) - 1;
+    sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col_ok && g.q_scale) {
+      sc = *reinterpret_cast<const float4*>(g.q_scale + c2);
+      sh = *reinterpret_cast<const float4*>(g.q_shift + c2);
+    }
+  }
   __device__ __forceinline__ void fetch(int kt, float4 (&r)[V4]) const {
     const int HQ = 2 * g.Hs, WQ = 2 * g.Ws;
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      int kr, c4;
-      rc_pos<R>(v, kr, c4);
-      const int64_t m = (int64_t)kt * 32 + kr;
-      const int64_t col = n0 + 4 * c4;
+      const int64_t m = (int64_t)kt * 32 + kr0 + v * (1024 / R);
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < g.Mtot && col < g.NC) {
+      if (col_ok && m < g.Mtot) {
         const int b = (int)(m & ((1 << g.lw) - 1));
         const int a = (int)((m >> g.lw) & ((1 << g.lh) - 1));
         const int64_t n = m >> (g.lw + g.lh);
-        if (C1) {
-          // single channel: columns are the 16 taps; this chunk is filter row kh = col/4
-          const int kh = (int)(col >> 2);
-          const int hi = 2 * a - 1 + kh;
-          if (hi >= 0 && hi < HQ) {
-            const float* p = g.Q + (n * HQ + hi) * WQ;
-            float t[4];
-#pragma unroll
-            for (int kw = 0; kw < 4; ++kw) {
-              const int wi = 2 * b - 1 + kw;
-              t[kw] = (wi >= 0 && wi < WQ) ? p[wi] : 0.f;
-            }
-            val = make_float4(t[0], t[1], t[2], t[3]);
+        const int hi = 2 * a + dh, wi = 2 * b + dw;
+        if (hi >= 0 && hi < HQ && wi >= 0 && wi < WQ) {
+          val = *reinterpret_cast<const float4*>(g.Q + ((n * HQ + hi) * WQ + wi) * g.C2 + c2);
+          if (g.q_scale) {
+            val.x = fmaf(val.x, sc.x, sh.x); val.y = fmaf(val.y, sc.y, sh.y);
+            val.z = fmaf(val.z, sc.z, sh.z); val.w = fmaf(val.w, sc.w, sh.w);
           }
-        } else {
-          const int tap = (int)(col / g.C2);
-          const int c2 = (int)(col - (int64_t)tap * g.C2);
-          const int hi = 2 * a - 1 + (tap >> 2), wi = 2 * b - 1 + (tap & 3);
-          if (hi >= 0 && hi < HQ && wi >= 0 && wi < WQ) {
-            val = *reinterpret_cast<const float4*>(g.Q + ((n * HQ + hi) * WQ + wi) * g.C2 + c2);
-            val = affine_act4(val, g.q_scale, g.q_shift, c2, g.q_act);
+          if (g.q_act == DVAE_ACT_LRELU) {
+            val.x = lrelu(val.x); val.y = lrelu(val.y); val.z = lrelu(val.z); val.w = lrelu(val.w);
           }
         }
       }
@@ -415,7 +441,7 @@ struct WgradQLoader {
   }
 };
 
-template <class T, bool C1>
+template <class T>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * T::STAGE_FLOATS];
   const int64_t m0 = (int64_t)blockIdx.y * T::BM, n0 = (int64_t)blockIdx.x * T::BN;
@@ -425,8 +451,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs g) {
   if (kt_end > ktiles) kt_end = ktiles;
   f32x16 acc[T::TM][T::TN];
   zero_acc<T>(acc);
-  WgradPLoader<T::A_V4, T::BM> la{g, m0};
-  WgradQLoader<T::B_V4, T::BN, C1> lb{g, n0};
+  WgradPLoader<T::A_V4, T::BM> la(g, m0);
+  WgradQLoader<T::B_V4, T::BN> lb(g, n0);
   gemm_mainloop<T>(la, lb, kt_begin, kt_end, smem, acc);
   float* dst = g.slab + (int64_t)blockIdx.z * g.C1 * g.NC;
   for_each_acc<T>(acc, [&](int r, int c, float v) {
@@ -435,38 +461,144 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs g) {
   });
 }
 
-// dw[(c1*C2 + c2)*16 + tap] = sum_z slab[z][c1][tap*C2 + c2]
+// Single-channel Q (first encoder conv, final decoder layer): dw[c1][tap] = sum_m P[m][c1] * q(m,tap).
+// Sixteen taps make this a reduction bound by the read of P, not a GEMM worth tiling through LDS:
+// each wave streams its own pixels straight from memory into v_mfma_f32_16x16x4_f32 operands
+// (A = P^T: 16 channels x 4 pixels, exactly how P lies in memory; B = 4 pixels x 16 taps gathered
+// from the single-channel image), accumulates [channels][taps] in registers over its whole pixel
+// range and the four waves' partials are summed through LDS once at the end.
+#define WG1_MAX_CB 8   // up to 128 channels
+template <int NCB, int U>
+__global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(WgradArgs g) {
+  __shared__ float red[4 * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, kq = lane >> 4;
+  constexpr int ncb = NCB;
+  const int HQ = 2 * g.Hs, WQ = 2 * g.Ws;
+  const int kh = i16 >> 2, kw = i16 & 3;       // this lane's tap as a B-operand column
+  f32x4 acc[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float psc[NCB], psh[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int c = cb * 16 + i16;
+    const bool ok = cb < ncb && c < g.C1 && g.p_scale != nullptr;
+    psc[cb] = ok ? g.p_scale[c] : 1.f;
+    psh[cb] = ok ? g.p_shift[c] : 0.f;
+  }
+  const int64_t nblk = (g.Mtot + 3) / 4;        // blocks of 4 pixels
+  const int64_t wid = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
+  // U pixel blocks per iteration: all their loads are issued before the first MFMA
+  for (int64_t blk = wid; blk < nblk; blk += U * nw) {
+    float qv[U], pv[U][NCB];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t m = (blk + u * nw) * 4 + kq;
+      const bool mok = (blk + u * nw) < nblk && m < g.Mtot;
+      qv[u] = 0.f;
+      if (mok) {
+        const int b = (int)(m & ((1 << g.lw) - 1));
+        const int a = (int)((m >> g.lw) & ((1 << g.lh) - 1));
+        const int64_t n = m >> (g.lw + g.lh);
+        const int hi = 2 * a - 1 + kh, wi = 2 * b - 1 + kw;
+        if (hi >= 0 && hi < HQ && wi >= 0 && wi < WQ) qv[u] = g.Q[(n * HQ + hi) * WQ + wi];
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        pv[u][cb] = 0.f;
+        if (cb < ncb) {
+          const int c = cb * 16 + i16;
+          if (mok && c < g.C1) pv[u][cb] = g.P[m * g.C1 + c];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t m = (blk + u * nw) * 4 + kq;
+      const bool mok = (blk + u * nw) < nblk && m < g.Mtot;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        if (cb < ncb) {
+          float v = pv[u][cb];
+          if (mok && cb * 16 + i16 < g.C1) {
+            if (g.p_scale) v = fmaf(v, psc[cb], psh[cb]);
+            if (g.p_act == DVAE_ACT_LRELU) v = lrelu(v);
+          } else {
+            v = 0.f;
+          }
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, qv[u], acc[cb], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D layout: column (tap) = lane & 15, row (channel in block) = (lane >> 4) * 4 + reg.
+  // Sum the four waves' partial tiles through LDS, one 16-channel block at a time.
+  float* dst = g.slab + (int64_t)blockIdx.x * g.C1 * 16;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    if (cb < ncb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * 16 + kq * 4 + r) * 16 + i16] = acc[cb][r];
+      __syncthreads();
+      const int c = cb * 16 + (threadIdx.x >> 4), tap = threadIdx.x & 15;
+      if (c < g.C1) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[(w * 16 + (threadIdx.x >> 4)) * 16 + tap];
+        dst[c * 16 + tap] = s;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// dw[(c1*C2 + c2)*16 + tap] = sum_z slab[z][c1][tap*C2 + c2]; threads walk the slab layout so the
+// reads of every slab are contiguous
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ slab, int split, float* __restrict__ dw, int64_t C1, int64_t C2) {
   const int64_t total = C1 * C2 * 16;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t tap = i & 15, c2 = (i >> 4) % C2, c1 = i / (16 * C2);
-    const int64_t src = c1 * (16 * C2) + tap * C2 + c2;
-    float s = 0.f;
-    for (int z = 0; z < split; ++z) s += slab[(int64_t)z * total + src];
-    dw[i] = s;
+    const int64_t c2 = i % C2, tap = (i / C2) & 15, c1 = i / (16 * C2);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 4 <= split; z += 4) {
+      s0 += slab[(int64_t)z * total + i];
+      s1 += slab[(int64_t)(z + 1) * total + i];
+      s2 += slab[(int64_t)(z + 2) * total + i];
+      s3 += slab[(int64_t)(z + 3) * total + i];
+    }
+    for (; z < split; ++z) s0 += slab[(int64_t)z * total + i];
+    dw[(c1 * C2 + c2) * 16 + tap] = (s0 + s1) + (s2 + s3);
   }
 }
 
 struct WgradPlan {
-  int bm;       // 32, 64 or 128
-  int bn;       // 32 or 128
+  int bm;       // 32, 64 or 128; 0 = single-channel streaming kernel
   int64_t tm, tn;
   int split, ktiles_per_split;
 };
 
 static WgradPlan wgrad_plan(int64_t Mtot, int64_t C1, int64_t C2) {
   WgradPlan p;
+  if (C2 == 1 && C1 <= 16 * WG1_MAX_CB) {
+    p.bm = 0;
+    p.tm = p.tn = 1;
+    int64_t blocks = ceil_div64(Mtot, 4 * 4 * 16);      // >= 16 four-pixel blocks per wave
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    p.split = (int)blocks;
+    p.ktiles_per_split = 0;
+    return p;
+  }
   const int64_t NC = 16 * C2;
-  p.bn = NC <= 32 ? 32 : 128;
-  if (p.bn == 32) p.bm = 128;            // 4 waves along M
-  else p.bm = C1 <= 32 ? 32 : (C1 <= 64 ? 64 : 128);
+  p.bm = C1 <= 32 ? 32 : (C1 <= 64 ? 64 : 128);
   p.tm = ceil_div64(C1, p.bm);
-  p.tn = ceil_div64(NC, p.bn);
+  p.tn = ceil_div64(NC, 128);
   const int64_t ktiles = ceil_div64(Mtot, 32);
-  int64_t s = 1024 / (p.tm * p.tn);
+  int64_t s = 768 / (p.tm * p.tn);
   if (s > ktiles / 8) s = ktiles / 8;
-  if (s > 512) s = 512;
+  if (s > 256) s = 256;
   if (s < 1) s = 1;
   p.ktiles_per_split = (int)ceil_div64(ktiles, s);
   p.split = (int)ceil_div64(ktiles, p.ktiles_per_split);
@@ -488,6 +620,7 @@ extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, cons
   DVAE_REQUIRE(C2 == 1 || C2 % 4 == 0, "conv4s2_wgrad: C2 must be 1 or a multiple of 4 (C2=%ld)", (long)C2);
   DVAE_REQUIRE(!(C2 == 1 && (q_scale != nullptr || q_act != DVAE_ACT_NONE)),
                "conv4s2_wgrad: no load-time transform on a single-channel Q");
+  DVAE_REQUIRE(!(C2 == 1 && C1 > 16 * WG1_MAX_CB), "conv4s2_wgrad: single-channel Q supports C1 <= %d", 16 * WG1_MAX_CB);
   DVAE_REQUIRE(aligned16(P) && aligned16(Q) && ws != nullptr, "conv4s2_wgrad: P, Q must be 16-byte aligned, ws non-null");
   WgradArgs g;
   g.P = P; g.p_scale = p_scale; g.p_shift = p_shift; g.p_act = p_act;
@@ -496,17 +629,23 @@ extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, cons
   g.C1 = (int)C1; g.C2 = (int)C2; g.NC = (int)(16 * C2);
   const WgradPlan p = wgrad_plan(g.Mtot, C1, C2);
   g.ktiles_per_split = p.ktiles_per_split;
-  const dim3 grid((unsigned)p.tn, (unsigned)p.tm, (unsigned)p.split);
   hipStream_t s = ST(stream);
-  if (p.bn == 32) {
-    if (C2 == 1) hipLaunchKernelGGL((conv_wgrad_kernel<Tile<128, 32, 4, 1, false, false>, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<Tile<128, 32, 4, 1, false, false>, false>), grid, dim3(256), 0, s, g);
-  } else if (p.bm == 32) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<Tile<32, 128, 1, 4, false, false>, false>), grid, dim3(256), 0, s, g);
-  } else if (p.bm == 64) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<Tile<64, 128, 2, 2, false, false>, false>), grid, dim3(256), 0, s, g);
+  if (p.bm == 0) {
+    const int ncb = (int)((C1 + 15) / 16);
+    const dim3 grid((unsigned)p.split);
+    if (ncb <= 1) hipLaunchKernelGGL((conv_wgrad_c1_kernel<1, 8>), grid, dim3(256), 0, s, g);
+    else if (ncb <= 2) hipLaunchKernelGGL((conv_wgrad_c1_kernel<2, 8>), grid, dim3(256), 0, s, g);
+    else if (ncb <= 4) hipLaunchKernelGGL((conv_wgrad_c1_kernel<4, 4>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((conv_wgrad_c1_kernel<8, 2>), grid, dim3(256), 0, s, g);
   } else {
-    hipLaunchKernelGGL((conv_wgrad_kernel<Tile<128, 128, 2, 2, false, false>, false>), grid, dim3(256), 0, s, g);
+    const dim3 grid((unsigned)p.tn, (unsigned)p.tm, (unsigned)p.split);
+    if (p.bm == 32) {
+      hipLaunchKernelGGL((conv_wgrad_kernel<Tile<32, 128, 1, 4, false, false>>), grid, dim3(256), 0, s, g);
+    } else if (p.bm == 64) {
+      hipLaunchKernelGGL((conv_wgrad_kernel<Tile<64, 128, 2, 2, false, false>>), grid, dim3(256), 0, s, g);
+    } else {
+      hipLaunchKernelGGL((conv_wgrad_kernel<Tile<128, 128, 2, 2, false, false>>), grid, dim3(256), 0, s, g);
+    }
   }
   DVAE_LAUNCH_CHECK("conv4s2_wgrad");
   int64_t nb = ceil_div64(C1 * C2 * 16, 256);
@@ -517,52 +656,91 @@ extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// final decoder layer: ConvTranspose2d(Cin -> 1) + bias + sigmoid.  One output channel, so this is
-// a dot-product kernel bound by the read of x, not a GEMM: one lane per output pixel, 2x2 taps of
-// Cin channels each, the four taps' weights for the pixel's phase held in LDS.
+// final decoder layer: ConvTranspose2d(Cin -> 1) + bias + sigmoid.
+//
+// Written in scatter form, every input pixel contributes x[pixel][:] . w[:][kh][kw] to the sixteen
+// output positions (2a-1+kh, 2b-1+kw): contributions[16 taps][pixels] = W^T[16 x Cin] * X^T[Cin x
+// pixels], a GEMM with exactly sixteen rows, which v_mfma_f32_16x16x4_f32 computes for sixteen pixels
+// at a time while x is read once, 16 B per lane, straight into the B operand.  A workgroup owns a
+// band of R input rows of one frame (plus one halo row on each side), accumulates the contributions
+// in an LDS image of the 2R output rows with ds_add_f32, then applies bias + sigmoid and writes the
+// rows out contiguously.  Bound by the read of x.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-deconv_final_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
-                    const float* __restrict__ in_shift, int in_act, const float* __restrict__ w,
-                    const float* __restrict__ bias, int out_act, float* __restrict__ y, int64_t total, int H, int W,
-                    int lh, int lw, int Cin) {
-  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [4 phases][4 taps][Cin]
-  for (int i = threadIdx.x; i < 16 * Cin; i += 256) {
-    const int ci = i % Cin, tap = (i / Cin) & 3, phase = i / (4 * Cin);
-    const int ph = phase >> 1, pw = phase & 1, th = tap >> 1, tw = tap & 1;
-    const int kh = ph == 0 ? (th == 0 ? 1 : 3) : (th == 0 ? 0 : 2);
-    const int kw = pw == 0 ? (tw == 0 ? 1 : 3) : (tw == 0 ? 0 : 2);
-    wsm[i] = w[(ci * 4 + kh) * 4 + kw];
-  }
-  __syncthreads();
-  const float bv = bias ? bias[0] : 0.f;
-  const int HO = 2 * H, WO = 2 * W;
-  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
-    const int wo = (int)(o & (WO - 1));
-    const int ho = (int)((o >> (lw + 1)) & (HO - 1));
-    const int64_t n = o >> (lw + lh + 2);
-    const int ph = ho & 1, pw = wo & 1, a = ho >> 1, b = wo >> 1;
-    const float* wph = wsm + (ph * 2 + pw) * 4 * Cin;
-    float acc = 0.f;
+#define DF_MAX_CB 16   // Cin <= 256
+struct DeconvFinalArgs {
+  const float* x;
+  const float* in_scale;
+  const float* in_shift;
+  const float* w;
+  const float* bias;
+  float* y;
+  int in_act, out_act;
+  int H, W, lw, Cin, R, bands;
+};
+
+__global__ void __launch_bounds__(256) deconv_final_kernel(DeconvFinalArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];      // [2R][2W + 2]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j16 = lane & 15, q = lane >> 4;
+  const int W = g.W, H = g.H, WO = 2 * W, LD = WO + 2;
+  const int64_t n = blockIdx.x / g.bands;
+  const int a0 = (int)(blockIdx.x % g.bands) * g.R;
+  const int ncb = (g.Cin + 15) / 16;
+  for (int i = threadIdx.x; i < 2 * g.R * LD; i += 256) tile[i] = 0.f;
+  // A operand: w[ci][tap] for tap = lane&15 and the four channels 4q..4q+3 of every 16-channel block
+  float wa[DF_MAX_CB][4];
 #pragma unroll
-    for (int tap = 0; tap < 4; ++tap) {
-      const int hi = a + ph - (tap >> 1), wi = b + pw - (tap & 1);
-      if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
-      const float* px = x + ((n * H + hi) * W + wi) * Cin;
-      const float* wt = wph + tap * Cin;
-      for (int ci = 0; ci < Cin; ci += 4) {
-        float4 v = *reinterpret_cast<const float4*>(px + ci);
-        v = affine_act4(v, in_scale, in_shift, ci, in_act);
-        const float4 ww = *reinterpret_cast<const float4*>(wt + ci);
-        acc = fmaf(v.x, ww.x, acc);
-        acc = fmaf(v.y, ww.y, acc);
-        acc = fmaf(v.z, ww.z, acc);
-        acc = fmaf(v.w, ww.w, acc);
+  for (int cb = 0; cb < DF_MAX_CB; ++cb)
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const int ci = cb * 16 + 4 * q + s2;
+      wa[cb][s2] = (cb < ncb && ci < g.Cin) ? g.w[ci * 16 + j16] : 0.f;
+    }
+  __syncthreads();
+  const int rows_in = g.R + 2;                   // halo row above and below
+  const int nblk = (rows_in * W + 15) / 16;
+  for (int blk = wave; blk < nblk; blk += 4) {
+    const int p = blk * 16 + j16;                // pixel of this lane inside the band (with halo)
+    const int ar = p >> g.lw, b = p & (W - 1);
+    const int a = a0 - 1 + ar;
+    const bool ok = ar < rows_in && a >= 0 && a < H;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* px = g.x + ((n * H + (ok ? a : 0)) * W + b) * g.Cin;
+#pragma unroll
+    for (int cb = 0; cb < DF_MAX_CB; ++cb) {
+      if (cb < ncb) {
+        const int ci = cb * 16 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && ci < g.Cin) {
+          v = *reinterpret_cast<const float4*>(px + ci);
+          v = affine_act4(v, g.in_scale, g.in_shift, ci, g.in_act);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][0], v.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][1], v.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][2], v.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][3], v.w, acc, 0, 0, 0);
       }
     }
-    acc += bv;
-    if (out_act == DVAE_ACT_SIGMOID) acc = 1.f / (1.f + expf(-acc));
-    y[o] = acc;
+    // D: column = pixel j16, row = tap = 4q + r  ->  kh = q, kw = r
+    if (ok) {
+      const int orow = 2 * a - 1 + q - 2 * a0;   // row inside the band's output image
+      if (orow >= 0 && orow < 2 * g.R) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ocol = 2 * b - 1 + r;
+          if (ocol >= 0 && ocol < WO) atomicAdd(&tile[orow * LD + ocol], acc[r]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const float bv = g.bias ? g.bias[0] : 0.f;
+  float* yo = g.y + (n * 2 * H + 2 * a0) * WO;
+  for (int i = threadIdx.x; i < 2 * g.R * WO; i += 256) {
+    const int r = i / WO, c = i - r * WO;
+    float v = tile[r * LD + c] + bv;
+    if (g.out_act == DVAE_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+    yo[i] = v;
   }
 }
 
@@ -571,13 +749,17 @@ extern "C" int dvae_deconv4s2_final_fwd_f32(const float* x, const float* in_scal
                                             int64_t H, int64_t W, int64_t Cin, dvae_stream_t stream) {
   DVAE_REQUIRE(N > 0, "deconv4s2_final_fwd: empty");
   DVAE_REQUIRE(is_pow2(H) && is_pow2(W), "deconv4s2_final_fwd: H and W must be powers of two");
-  DVAE_REQUIRE(Cin % 4 == 0 && Cin <= 1024, "deconv4s2_final_fwd: Cin must be a multiple of 4, at most 1024 (Cin=%ld)", (long)Cin);
+  DVAE_REQUIRE(Cin % 4 == 0 && Cin <= 16 * DF_MAX_CB, "deconv4s2_final_fwd: Cin must be a multiple of 4, at most %d (Cin=%ld)",
+               16 * DF_MAX_CB, (long)Cin);
   DVAE_REQUIRE(aligned16(x), "deconv4s2_final_fwd: x must be 16-byte aligned");
-  const int64_t total = N * 4 * H * W;
-  int64_t nb = ceil_div64(total, 256);
-  if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(deconv_final_kernel, dim3((unsigned)nb), dim3(256), (size_t)(16 * Cin * 4), ST(stream), x, in_scale,
-                     in_shift, in_act, w, bias, out_act, y, total, (int)H, (int)W, ilog2(H), ilog2(W), (int)Cin);
+  DVAE_REQUIRE(W <= 512, "deconv4s2_final_fwd: W too large for the LDS band image");
+  DeconvFinalArgs g;
+  g.x = x; g.in_scale = in_scale; g.in_shift = in_shift; g.w = w; g.bias = bias; g.y = y;
+  g.in_act = in_act; g.out_act = out_act; g.H = (int)H; g.W = (int)W; g.lw = ilog2(W); g.Cin = (int)Cin;
+  g.R = H >= 8 ? 8 : (int)H;
+  g.bands = (int)(H / g.R);
+  const size_t lds = (size_t)(2 * g.R) * (2 * W + 2) * 4;
+  hipLaunchKernelGGL(deconv_final_kernel, dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);
   DVAE_LAUNCH_CHECK("deconv4s2_final_fwd");
   return 0;
 }
