@@ -247,6 +247,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-table', action='store_true')
     ap.add_argument('--bucket-mb', type=float, default=16.0)
+    ap.add_argument('--graph', type=int, default=-1, help='1: replay a captured hipGraph per step; 0: eager; '
+                    '-1: graph on one GPU, eager (overlapped all-reduce) on several')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -301,9 +303,17 @@ def main():
         with torch.no_grad():
             return model(ring[i % len(ring)])
 
+    use_graph = args.mode == 'train' and (args.graph == 1 or (args.graph == -1 and world == 1))
+    if use_graph and world > 1:
+        raise SystemExit("--graph 1 is single-GPU only for now (the all-reduce is launched from autograd hooks)")
     if args.mode == 'train':
         model.train()
         step = train_step
+        if use_graph:
+            from hipvae.graph import GraphedTrainStep
+            gstep = GraphedTrainStep(model, opt, lambda m, v: loss_call(kind, L, m(v), v, t, beta), ring[0],
+                                     gradient_clip=t['gradient_clip'])
+            step = lambda i: gstep(ring[i % len(ring)])
     else:
         model.eval()
         step = infer_step
@@ -334,13 +344,15 @@ def main():
         'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f"{cfg['name']} ({args.config}) {args.mode} step, beta=4, {T}x{size}x{size} clips, "
-                               f"batch {B}/GPU, fp32 MFMA", 'global_batch': B * world, 'params': n_params,
+                               f"batch {B}/GPU, fp32 MFMA, {'hipGraph replay' if use_graph else 'eager launches'}",
+                   'global_batch': B * world, 'params': n_params,
                    'parallelism': f'dp{world}'},
     }
     if args.mode == 'train':
         result['loss'] = round(float(last['total_loss'].item()), 3)
 
     if rank == 0 and world == 1 and not args.no_kernel_table:
+        step = train_step if args.mode == 'train' else infer_step      # kernels are timed on eager launches
         kt = KernelTimer(ops)
         kt.install()
         nprof = 3

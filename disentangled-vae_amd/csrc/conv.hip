@@ -662,9 +662,10 @@ extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, cons
 // output positions (2a-1+kh, 2b-1+kw): contributions[16 taps][pixels] = W^T[16 x Cin] * X^T[Cin x
 // pixels], a GEMM with exactly sixteen rows, which v_mfma_f32_16x16x4_f32 computes for sixteen pixels
 // at a time while x is read once, 16 B per lane, straight into the B operand.  A workgroup owns a
-// band of R input rows of one frame (plus one halo row on each side), accumulates the contributions
-// in an LDS image of the 2R output rows with ds_add_f32, then applies bias + sigmoid and writes the
-// rows out contiguously.  Bound by the read of x.
+// band of R input rows of one frame (plus one halo row on each side), parks the sixteen tap products
+// of every pixel in LDS, then each output position sums the four that reach it in a fixed order
+// (bit-reproducible, no atomics), applies bias + sigmoid and the 2R output rows are written out
+// contiguously.  Bound by the read of x.
 // ------------------------------------------------------------------------------------------------
 #define DF_MAX_CB 16   // Cin <= 256
 struct DeconvFinalArgs {
@@ -679,14 +680,13 @@ struct DeconvFinalArgs {
 };
 
 __global__ void __launch_bounds__(256) deconv_final_kernel(DeconvFinalArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];      // [2R][2W + 2]
+  extern __shared__ __attribute__((aligned(16))) float contrib[];   // [(R+2)*W pixels][16 taps]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j16 = lane & 15, q = lane >> 4;
-  const int W = g.W, H = g.H, WO = 2 * W, LD = WO + 2;
+  const int W = g.W, H = g.H, WO = 2 * W;
   const int64_t n = blockIdx.x / g.bands;
   const int a0 = (int)(blockIdx.x % g.bands) * g.R;
   const int ncb = (g.Cin + 15) / 16;
-  for (int i = threadIdx.x; i < 2 * g.R * LD; i += 256) tile[i] = 0.f;
   // A operand: w[ci][tap] for tap = lane&15 and the four channels 4q..4q+3 of every 16-channel block
   float wa[DF_MAX_CB][4];
 #pragma unroll
@@ -721,24 +721,34 @@ __global__ void __launch_bounds__(256) deconv_final_kernel(DeconvFinalArgs g) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][3], v.w, acc, 0, 0, 0);
       }
     }
-    // D: column = pixel j16, row = tap = 4q + r  ->  kh = q, kw = r
-    if (ok) {
-      const int orow = 2 * a - 1 + q - 2 * a0;   // row inside the band's output image
-      if (orow >= 0 && orow < 2 * g.R) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ocol = 2 * b - 1 + r;
-          if (ocol >= 0 && ocol < WO) atomicAdd(&tile[orow * LD + ocol], acc[r]);
-        }
-      }
-    }
+    // D: column = pixel j16, row = tap = 4q + r  ->  this lane holds kh = q, kw = 0..3 of its pixel
+    if (ar < rows_in)
+      *reinterpret_cast<float4*>(contrib + (int64_t)p * 16 + 4 * q) =
+          ok ? make_float4(acc[0], acc[1], acc[2], acc[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
+  // gather: output (ho, wo) = sum over the 2x2 input pixels that reach it, in a fixed order
   const float bv = g.bias ? g.bias[0] : 0.f;
   float* yo = g.y + (n * 2 * H + 2 * a0) * WO;
   for (int i = threadIdx.x; i < 2 * g.R * WO; i += 256) {
-    const int r = i / WO, c = i - r * WO;
-    float v = tile[r * LD + c] + bv;
+    const int orow = i / WO, wo = i - orow * WO;
+    const int ho = 2 * a0 + orow;
+    // rows: ho even -> (a = ho/2, kh = 1), (a = ho/2 - 1, kh = 3); ho odd -> (a = (ho+1)/2, kh = 0), (a = (ho-1)/2, kh = 2)
+    const int ah = (ho + 1) >> 1, khh = (ho & 1) ? 0 : 1;
+    const int bh = (wo + 1) >> 1, kwh = (wo & 1) ? 0 : 1;
+    float v = bv;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const int a = ah - dy, kh = khh + 2 * dy;
+      if (a < 0 || a >= H) continue;
+      const int ar = a - (a0 - 1);
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int b = bh - dx, kw = kwh + 2 * dx;
+        if (b < 0 || b >= W) continue;
+        v += contrib[(ar * W + b) * 16 + kh * 4 + kw];
+      }
+    }
     if (g.out_act == DVAE_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
     yo[i] = v;
   }
@@ -752,13 +762,13 @@ extern "C" int dvae_deconv4s2_final_fwd_f32(const float* x, const float* in_scal
   DVAE_REQUIRE(Cin % 4 == 0 && Cin <= 16 * DF_MAX_CB, "deconv4s2_final_fwd: Cin must be a multiple of 4, at most %d (Cin=%ld)",
                16 * DF_MAX_CB, (long)Cin);
   DVAE_REQUIRE(aligned16(x), "deconv4s2_final_fwd: x must be 16-byte aligned");
-  DVAE_REQUIRE(W <= 512, "deconv4s2_final_fwd: W too large for the LDS band image");
+  DVAE_REQUIRE(W <= 128, "deconv4s2_final_fwd: W too large for the LDS band image");
   DeconvFinalArgs g;
   g.x = x; g.in_scale = in_scale; g.in_shift = in_shift; g.w = w; g.bias = bias; g.y = y;
   g.in_act = in_act; g.out_act = out_act; g.H = (int)H; g.W = (int)W; g.lw = ilog2(W); g.Cin = (int)Cin;
   g.R = H >= 8 ? 8 : (int)H;
   g.bands = (int)(H / g.R);
-  const size_t lds = (size_t)(2 * g.R) * (2 * W + 2) * 4;
+  const size_t lds = (size_t)(g.R + 2) * W * 16 * 4;
   hipLaunchKernelGGL(deconv_final_kernel, dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);
   DVAE_LAUNCH_CHECK("deconv4s2_final_fwd");
   return 0;

@@ -81,9 +81,18 @@ mt_scale_kernel(MTTable t, const float* __restrict__ coef) {
   for (int64_t i = base + threadIdx.x; i < end; i += 256) g[i] *= c;
 }
 
+// `dyn` (optional, device): {step count, learning rate}.  When given, the bias corrections and the
+// step size are derived from it inside the kernel, so a captured graph replays correctly as the
+// step count and the learning rate move; the host-side scalars are ignored.
 __global__ void __launch_bounds__(256)
 mt_adam_kernel(MTTable t, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
-               const float* __restrict__ grad_coef) {
+               const float* __restrict__ grad_coef, const float* __restrict__ dyn) {
+  if (dyn) {
+    const float step = dyn[0];
+    lr = dyn[1];
+    bc1 = 1.f - powf(beta1, step);
+    bc2_sqrt = sqrtf(1.f - powf(beta2, step));
+  }
   const int ti = mt_find(t, blockIdx.x);
   const int64_t base = (int64_t)(blockIdx.x - t.chunk_start[ti]) * MT_CHUNK;
   const int64_t n = t.numel[ti];
@@ -181,12 +190,24 @@ extern "C" int dvae_scale_tensors_f32(int64_t n, float* const* tensors, const in
   return 0;
 }
 
+__global__ void adam_advance_kernel(float* dyn) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) dyn[0] += 1.f;
+}
+
+extern "C" int dvae_adam_advance_f32(float* dyn, dvae_stream_t stream) {
+  DVAE_REQUIRE(dyn != nullptr, "adam_advance: null state");
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, ST(stream), dyn);
+  DVAE_LAUNCH_CHECK("adam_advance");
+  return 0;
+}
+
 extern "C" int dvae_adam_step_f32(int64_t n, float* const* params, const float* const* grads, float* const* exp_avg,
                                   float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2,
                                   float eps, float weight_decay, float bias_correction1, float bias_correction2,
-                                  const float* grad_coef, dvae_stream_t stream) {
+                                  const float* grad_coef, const float* dyn, dvae_stream_t stream) {
   DVAE_REQUIRE(n > 0, "adam_step: no tensors");
-  DVAE_REQUIRE(bias_correction1 > 0.f && bias_correction2 > 0.f, "adam_step: bias corrections must be positive");
+  DVAE_REQUIRE(dyn != nullptr || (bias_correction1 > 0.f && bias_correction2 > 0.f),
+               "adam_step: bias corrections must be positive");
   const float bc2_sqrt = sqrtf(bias_correction2);
   for (int64_t first = 0; first < n; first += MT_MAX) {
     MTTable t;
@@ -198,7 +219,7 @@ extern "C" int dvae_adam_step_f32(int64_t n, float* const* params, const float* 
       t.v[i] = (void*)exp_avg_sq[first + i];
     }
     hipLaunchKernelGGL(mt_adam_kernel, dim3(blocks), dim3(256), 0, ST(stream), t, lr, beta1, beta2, eps, weight_decay,
-                       bias_correction1, bc2_sqrt, grad_coef);
+                       bias_correction1, bc2_sqrt, grad_coef, dyn);
     DVAE_LAUNCH_CHECK("adam_step");
   }
   return 0;

@@ -70,7 +70,8 @@ SIGNATURES = {
     'dvae_grad_norm_f32': (I, [L, POINTER(c_void_p), POINTER(c_int64), F, P, P, P]),
     'dvae_scale_tensors_f32': (I, [L, POINTER(c_void_p), POINTER(c_int64), P, P]),
     'dvae_adam_step_f32': (I, [L, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
-                               POINTER(c_int64), F, F, F, F, F, F, F, P, P]),
+                               POINTER(c_int64), F, F, F, F, F, F, F, P, P, P]),
+    'dvae_adam_advance_f32': (I, [P, P]),
 }
 
 MISSING = []

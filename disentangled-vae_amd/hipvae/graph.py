@@ -1,0 +1,71 @@
+"""Whole-step hipGraph capture: zero_grad + forward + loss + backward + clip + Adam recorded once and
+replayed per batch, which removes the per-launch host cost (several hundred kernel launches per step;
+the batch-32 configurations are launch-bound without it).
+
+Captured through torch.cuda.graph (HIP graphs on ROCm): every kernel of libdvae_hip.so is launched on
+torch's current stream, so it is recorded like any torch op.  What changes from step to step lives in
+device memory: the input clip (a static buffer the batch is copied into), the Adam step count and
+learning rate (FusedAdam.enable_device_state) and the random draws (torch's graph-safe generator).
+Values baked into the graph: shapes, loss weights (beta included: re-capture when beta changes).
+"""
+from typing import Callable, Dict, Optional
+
+import torch
+
+
+class GraphedTrainStep:
+
+    def __init__(self, model: torch.nn.Module, optimizer, loss_of: Callable, example_video: torch.Tensor,
+                 gradient_clip: float = 0.0, warmup: int = 2):
+        """loss_of(model, video) -> LossDict (must contain 'total_loss').  The warm-up steps needed
+        before capture run on the example batch and are undone afterwards: parameters, buffers and
+        optimiser state are restored in place, so capture does not count as training."""
+        self.model, self.opt, self.loss_of, self.clip = model, optimizer, loss_of, float(gradient_clip)
+        self.static_video = example_video.detach().clone()
+        tensors = list(model.parameters()) + list(model.buffers())
+        snap = [t.detach().clone() for t in tensors]
+        had_state = any(len(optimizer.state[p]) for p in model.parameters() if p in optimizer.state)
+        if had_state:
+            raise RuntimeError("capture the step before the first optimiser step (or after load_state_dict "
+                               "on a fresh optimiser)")
+        optimizer.enable_device_state()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.losses = self._step()
+        # undo the warm-up
+        with torch.no_grad():
+            for t, s in zip(tensors, snap):
+                t.copy_(s)
+            for st in optimizer.state.values():
+                if 'exp_avg' in st:
+                    st['exp_avg'].zero_()
+                    st['exp_avg_sq'].zero_()
+                    st['step'].zero_()
+            optimizer._replayed = 0
+            optimizer._dyn[0:1].zero_()
+        torch.cuda.synchronize()
+
+    def _step(self):
+        self.opt.zero_grad(set_to_none=True)
+        losses = self.loss_of(self.model, self.static_video)
+        losses['total_loss'].backward()
+        if self.clip > 0:
+            self.opt.clip_grad_norm_(self.clip, fold_into_step=True)
+        self.opt.step()
+        return losses
+
+    def __call__(self, video: torch.Tensor):
+        """One training step on `video` (same shape as the example).  Returns the static LossDict whose
+        device values are overwritten by every replay."""
+        self.static_video.copy_(video, non_blocking=True)
+        self.opt.sync_device_lr()
+        self.graph.replay()
+        self.opt.note_replayed_step()
+        return self.losses

@@ -36,6 +36,7 @@ def _p(t: Optional[Tensor]):
 
 
 _WS = {}
+_WS_RETIRED = []
 
 
 def workspace(nfloats: int, device, slot: str = 'main') -> Tensor:
@@ -43,6 +44,8 @@ def workspace(nfloats: int, device, slot: str = 'main') -> Tensor:
     key = (torch.device(device).index, slot)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
+        if buf is not None:
+            _WS_RETIRED.append(buf)      # a captured graph may still point at it: never hand it back
         buf = torch.empty(max(int(nfloats), 1024), dtype=torch.float32, device=device)
         _WS[key] = buf
     return buf
@@ -423,9 +426,14 @@ def scale_tensors(tensors: List[Tensor], coef: Tensor, table: Optional[TensorTab
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
-              grad_coef: Optional[Tensor], table: Optional[TensorTable] = None):
+              grad_coef: Optional[Tensor], table: Optional[TensorTable] = None, dyn: Optional[Tensor] = None):
+    """dyn: device tensor {step count, learning rate}; when given it overrides lr/bc1/bc2."""
     table = table or TensorTable()
     n, (p, g, m, v), numel = table.get([params, grads, exp_avg, exp_avg_sq])
     check(lib.dvae_adam_step_f32(n, p, g, m, v, numel, float(lr), float(beta1), float(beta2), float(eps),
-                                 float(weight_decay), float(bc1), float(bc2), _p(grad_coef), _stream()),
+                                 float(weight_decay), float(bc1), float(bc2), _p(grad_coef), _p(dyn), _stream()),
           'adam_step')
+
+
+def adam_advance(dyn: Tensor):
+    check(lib.dvae_adam_advance_f32(_p(dyn), _stream()), 'adam_advance')

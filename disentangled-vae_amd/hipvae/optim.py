@@ -20,6 +20,53 @@ class FusedAdam(torch.optim.Adam):
         self._tables = {}
         self._norm_out = None          # [norm, clip coefficient] on the device
         self._pending_coef = None
+        self._dyn = None               # device {step count, learning rate} for graph replay
+        self._dyn_lr = None
+        self._replayed = 0             # steps taken by graph replays, not yet written to state['step']
+
+    # ---- device-resident step state (needed when step() is captured into a hipGraph) -----------
+    def enable_device_state(self):
+        """Keep the step count and learning rate in device memory and let the Adam kernel derive its
+        bias corrections from them, so that a captured graph stays correct as they change."""
+        if len(self.param_groups) != 1:
+            raise RuntimeError("device-resident step state supports a single parameter group")
+        p0 = self.param_groups[0]['params'][0]
+        steps = 0.0
+        for p in self.param_groups[0]['params']:
+            if p in self.state and len(self.state[p]):
+                steps = float(self.state[p]['step'])
+                break
+        self._dyn = torch.tensor([steps, float(self.param_groups[0]['lr'])], dtype=torch.float32, device=p0.device)
+        self._dyn_lr = float(self.param_groups[0]['lr'])
+        return self._dyn
+
+    def sync_device_lr(self):
+        """Push a learning rate changed by a scheduler to the device copy (no-op when unchanged)."""
+        if self._dyn is not None:
+            lr = float(self.param_groups[0]['lr'])
+            if lr != self._dyn_lr:
+                self._dyn[1:2].fill_(lr)
+                self._dyn_lr = lr
+
+    def note_replayed_step(self):
+        self._replayed += 1
+
+    def _flush_replayed(self):
+        if self._replayed:
+            for st in self.state.values():
+                if 'step' in st:
+                    st['step'] += float(self._replayed)
+            self._replayed = 0
+
+    def state_dict(self):
+        self._flush_replayed()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        self._replayed = 0
+        super().load_state_dict(state_dict)
+        if self._dyn is not None:
+            self.enable_device_state()
 
     # ---- gradient clipping -------------------------------------------------------------------
     def _grads(self):
@@ -55,6 +102,9 @@ class FusedAdam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         coef, self._pending_coef = self._pending_coef, None
+        self._flush_replayed()
+        if self._dyn is not None:
+            ops.adam_advance(self._dyn)
         for gi, group in enumerate(self.param_groups):
             params, grads, m, v = [], [], [], []
             step_val = None
@@ -83,5 +133,5 @@ class FusedAdam(torch.optim.Adam):
             lr = float(lr) if not isinstance(lr, torch.Tensor) else float(lr.item())
             ops.adam_step(params, grads, m, v, lr, b1, b2, group['eps'], group['weight_decay'],
                           1.0 - b1 ** step_val, 1.0 - b2 ** step_val, coef,
-                          self._tables.setdefault(('adam', gi), ops.TensorTable()))
+                          self._tables.setdefault(('adam', gi), ops.TensorTable()), dyn=self._dyn)
         return loss
