@@ -85,17 +85,28 @@ struct ConvArgs {
   int lh, lw;    // log2 of the row-index grid (conv: Ho,Wo ; deconv: H,W)
   int Cin, Cout, K;
   int mtiles;
+  int lc;      // log2(Cin) when Cin is a power of two, else -1
+  int cin32;   // Cin % 32 == 0: a K tile never straddles two filter taps
 };
 
 // A operand of the forward implicit GEMMs.  MODE 0: conv (16 taps, input pixel 2*o-1+k);
 // MODE 1: transposed conv phase (4 taps, input pixel a+ph-th).  C1: single input channel.
+//
+// Per M tile each thread records, for each of its rows, the element offset of the row's anchor pixel
+// and one bit per filter tap saying whether that tap falls inside the frame.  A K tile then costs a
+// bit test and one address add per 16-byte load.  issue() only starts loads (masked-out chunks read
+// x[0..3], which is always there, and are zeroed in finish()); the BatchNorm scale/shift of the K
+// tile's channels ride along as two more loads in flight.  K tiles must be visited in order from 0.
 template <int V4, int MODE, bool C1>
 struct ConvALoader {
   const ConvArgs& g;
   int ph, pw;
-  int64_t base[V4];
-  int h0[V4], w0[V4];
-  bool ok[V4];
+  int64_t off0[V4];       // element offset of (n, h0, w0, channel 0)
+  unsigned tapmask[V4];
+  int h0[V4], w0[V4];     // single-channel path only
+  int tap, ci0;           // position of the current K tile (uniform path)
+  unsigned mask;
+  float4 sc, sh;
   __device__ __forceinline__ ConvALoader(const ConvArgs& g_, int ph_, int pw_) : g(g_), ph(ph_), pw(pw_) {}
   __device__ __forceinline__ void set_tile(int64_t m0) {
 #pragma unroll
@@ -103,67 +114,123 @@ struct ConvALoader {
       int row, ch;
       kc_pos(v, row, ch);
       const int64_t m = m0 + row;
-      ok[v] = m < g.M;
       const int b = (int)(m & ((1 << g.lw) - 1));
       const int a = (int)((m >> g.lw) & ((1 << g.lh) - 1));
       const int64_t n = m >> (g.lw + g.lh);
-      base[v] = n * g.H * g.W * g.Cin;
+      unsigned rowbits = 0, colbits = 0, bits;
+      int hh, ww;
       if (MODE == 0) {
-        h0[v] = 2 * a - 1;
-        w0[v] = 2 * b - 1;
+        hh = 2 * a - 1;
+        ww = 2 * b - 1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          rowbits |= (unsigned)(hh + d >= 0 && hh + d < g.H) << (4 * d);
+          colbits |= (unsigned)(ww + d >= 0 && ww + d < g.W) << d;
+        }
+        bits = rowbits * colbits;          // bit 4*dh + dw
       } else {
-        h0[v] = a + ph;
-        w0[v] = b + pw;
+        hh = a + ph;
+        ww = b + pw;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          rowbits |= (unsigned)(hh - d >= 0 && hh - d < g.H) << (2 * d);
+          colbits |= (unsigned)(ww - d >= 0 && ww - d < g.W) << d;
+        }
+        bits = rowbits * colbits;          // bit 2*th + tw
       }
+      tapmask[v] = m < g.M ? bits : 0u;
+      off0[v] = ((n * g.H + hh) * g.W + ww) * g.Cin;
+      h0[v] = hh;
+      w0[v] = ww;
     }
   }
-  __device__ __forceinline__ void fetch(int kt, float4 (&r)[V4]) const {
+  __device__ __forceinline__ void issue(int kt, float4 (&r)[V4]) {
     const int ch = threadIdx.x & 7;
-    const int k = kt * 32 + 4 * ch;
+    mask = 0;
     if (C1) {
       // K = 16 (conv only): k = kh*4 + kw, the chunk is one filter row
       const int kh = ch;
+      const bool kok = kt == 0 && kh < 4;
 #pragma unroll
       for (int v = 0; v < V4; ++v) {
-        float t[4] = {0.f, 0.f, 0.f, 0.f};
-        const int hi = h0[v] + kh;
-        if (ok[v] && k < g.K && hi >= 0 && hi < g.H) {
-          const float* p = g.x + base[v] + (int64_t)hi * g.W;
+        float t[4];
+        const unsigned bits = kok ? (tapmask[v] >> (4 * (kh & 3))) & 15u : 0u;
+        const float* p = g.x + off0[v] + kh * g.W;
 #pragma unroll
-          for (int kw = 0; kw < 4; ++kw) {
-            const int wi = w0[v] + kw;
-            if (wi >= 0 && wi < g.W) t[kw] = p[wi];
-          }
+        for (int kw = 0; kw < 4; ++kw) {
+          const bool eok = (bits >> kw) & 1u;
+          t[kw] = *(eok ? p + kw : g.x);
         }
+        mask |= bits << (4 * v);
         r[v] = make_float4(t[0], t[1], t[2], t[3]);
       }
       return;
     }
-    const int tap = k / g.Cin;
-    const int ci = k - tap * g.Cin;
-    int dh, dw;
-    if (MODE == 0) {
-      dh = tap >> 2;
-      dw = tap & 3;
+    int tp, ci;
+    bool kok;
+    if (g.cin32) {
+      if (kt == 0) {
+        tap = 0;
+        ci0 = 0;
+      } else {
+        ci0 += 32;
+        if (ci0 >= g.Cin) {
+          ci0 = 0;
+          ++tap;
+        }
+      }
+      tp = tap;
+      ci = ci0 + 4 * ch;
+      kok = kt * 32 < g.K;
     } else {
-      dh = -(tap >> 1);
-      dw = -(tap & 1);
+      const int k = kt * 32 + 4 * ch;
+      tp = g.lc >= 0 ? k >> g.lc : k / g.Cin;
+      ci = k - tp * g.Cin;
+      kok = k < g.K;
+    }
+    const int tapoff = MODE == 0 ? (tp >> 2) * g.W + (tp & 3) : -((tp >> 1) * g.W + (tp & 1));
+    const int toff = tapoff * g.Cin + ci;
+    if (g.in_scale) {
+      const int cs = kok ? ci : 0;
+      sc = *reinterpret_cast<const float4*>(g.in_scale + cs);
+      sh = *reinterpret_cast<const float4*>(g.in_shift + cs);
     }
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      const int hi = h0[v] + dh, wi = w0[v] + dw;
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok[v] && k < g.K && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) {
-        val = *reinterpret_cast<const float4*>(g.x + base[v] + ((int64_t)hi * g.W + wi) * g.Cin + ci);
-        val = affine_act4(val, g.in_scale, g.in_shift, ci, g.in_act);
+      const bool eok = kok && ((tapmask[v] >> tp) & 1u);
+      const float* p = eok ? g.x + (off0[v] + toff) : g.x;
+      r[v] = *reinterpret_cast<const float4*>(p);
+      mask |= (unsigned)eok << v;
+    }
+  }
+  __device__ __forceinline__ void finish(float4 (&r)[V4]) const {
+    if (C1) {
+#pragma unroll
+      for (int v = 0; v < V4; ++v) {
+        r[v].x = (mask >> (4 * v + 0)) & 1u ? r[v].x : 0.f;
+        r[v].y = (mask >> (4 * v + 1)) & 1u ? r[v].y : 0.f;
+        r[v].z = (mask >> (4 * v + 2)) & 1u ? r[v].z : 0.f;
+        r[v].w = (mask >> (4 * v + 3)) & 1u ? r[v].w : 0.f;
       }
-      r[v] = val;
+      return;
+    }
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      float4 val = r[v];
+      if (g.in_scale) {
+        val.x = fmaf(val.x, sc.x, sh.x); val.y = fmaf(val.y, sc.y, sh.y);
+        val.z = fmaf(val.z, sc.z, sh.z); val.w = fmaf(val.w, sc.w, sh.w);
+      }
+      if (g.in_act == DVAE_ACT_LRELU) {
+        val.x = lrelu(val.x); val.y = lrelu(val.y); val.z = lrelu(val.z); val.w = lrelu(val.w);
+      }
+      r[v] = zero_unless(val, (mask >> v) & 1u);
     }
   }
 };
 
 template <class T, int MODE, bool C1>
-__global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs g) {
+__global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * T::STAGE_FLOATS];
   // transposed conv: the four sub-pixel phases of one M tile sit in adjacent workgroups, so the input
   // tile they share is fetched from HBM once and re-read through L2
@@ -177,7 +244,7 @@ __global__ void __launch_bounds__(256) conv_fwd_kernel(ConvArgs g) {
   const int l31 = lane & 31;
 
   ConvALoader<T::A_V4, MODE, C1> la(g, ph, pw);
-  KCLoader<T::B_V4> lb{g.wp + (int64_t)phase * g.Cout * g.K, (int64_t)g.K, (int64_t)g.Cout, (int64_t)g.K, n0};
+  KCLoader<T::B_V4> lb(g.wp + (int64_t)phase * g.Cout * g.K, (int64_t)g.K, (int64_t)g.Cout, (int64_t)g.K, n0);
 
   float s1[T::TN], s2[T::TN];
 #pragma unroll
@@ -310,6 +377,8 @@ extern "C" int dvae_conv4s2_fwd_f32(const float* x, const float* in_scale, const
   g.in_act = in_act; g.H = (int)H; g.W = (int)W; g.lh = ilog2(H / 2); g.lw = ilog2(W / 2);
   g.Cin = (int)Cin; g.Cout = (int)Cout; g.K = (int)(16 * Cin);
   g.M = N * (H / 2) * (W / 2);
+  g.lc = is_pow2(Cin) ? ilog2(Cin) : -1;
+  g.cin32 = Cin % 32 == 0;
   return launch_conv_fwd<0>("conv4s2_fwd", g, 1, ST(stream));
 }
 
@@ -325,6 +394,8 @@ extern "C" int dvae_deconv4s2_fwd_f32(const float* x, const float* in_scale, con
   g.in_act = in_act; g.H = (int)H; g.W = (int)W; g.lh = ilog2(H); g.lw = ilog2(W);
   g.Cin = (int)Cin; g.Cout = (int)Cout; g.K = (int)(4 * Cin);
   g.M = N * H * W;
+  g.lc = is_pow2(Cin) ? ilog2(Cin) : -1;
+  g.cin32 = Cin % 32 == 0;
   return launch_conv_fwd<1>("deconv4s2_fwd", g, 4, ST(stream));
 }
 
@@ -354,16 +425,19 @@ struct WgradArgs {
 
 // Both operands of the weight-gradient GEMM are row-contiguous tiles whose column position is
 // fixed per thread for the whole K loop (256 % (R/4) == 0), so everything that depends on the column
-// (channel, filter tap, pixel offset) is computed once; per fetch only the pixel index m moves.
+// (channel, filter tap, pixel offset, which border rows the tap leaves the frame on) is computed
+// once; per K tile only the pixel index m moves.  With Hs, Ws powers of two the Q pixel of (m, tap)
+// sits at element ((4m - 2b) + dh*WQ + dw) * C2 of Q, b = m mod Ws.
 template <int V4, int R>
 struct WgradPLoader {
   const WgradArgs& g;
-  int64_t c;      // channel of this thread's 4-float chunk
+  int c;          // channel of this thread's 4-float chunk
   int kr0;
   bool col_ok;
+  unsigned mask;
   float4 sc, sh;
   __device__ __forceinline__ WgradPLoader(const WgradArgs& g_, int64_t c0) : g(g_) {
-    c = c0 + 4 * (threadIdx.x % (R / 4));
+    c = (int)c0 + 4 * (threadIdx.x % (R / 4));
     kr0 = threadIdx.x / (R / 4);
     col_ok = c < g.C1;
     sc = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -373,22 +447,29 @@ struct WgradPLoader {
       sh = *reinterpret_cast<const float4*>(g.p_shift + c);
     }
   }
-  __device__ __forceinline__ void fetch(int kt, float4 (&r)[V4]) const {
+  __device__ __forceinline__ void issue(int kt, float4 (&r)[V4]) {
+    mask = 0;
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      const int64_t m = (int64_t)kt * 32 + kr0 + v * (1024 / R);
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (col_ok && m < g.Mtot) {
-        val = *reinterpret_cast<const float4*>(g.P + m * g.C1 + c);
-        if (g.p_scale) {
-          val.x = fmaf(val.x, sc.x, sh.x); val.y = fmaf(val.y, sc.y, sh.y);
-          val.z = fmaf(val.z, sc.z, sh.z); val.w = fmaf(val.w, sc.w, sh.w);
-        }
-        if (g.p_act == DVAE_ACT_LRELU) {
-          val.x = lrelu(val.x); val.y = lrelu(val.y); val.z = lrelu(val.z); val.w = lrelu(val.w);
-        }
+      const unsigned m = (unsigned)(kt * 32 + v * (1024 / R)) + (unsigned)kr0;
+      const bool eok = col_ok && m < (unsigned)g.Mtot;
+      const float* p = eok ? g.P + ((uint64_t)m * (unsigned)g.C1 + (unsigned)c) : g.P;
+      r[v] = *reinterpret_cast<const float4*>(p);
+      mask |= (unsigned)eok << v;
+    }
+  }
+  __device__ __forceinline__ void finish(float4 (&r)[V4]) const {
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      float4 val = r[v];
+      if (g.p_scale) {
+        val.x = fmaf(val.x, sc.x, sh.x); val.y = fmaf(val.y, sc.y, sh.y);
+        val.z = fmaf(val.z, sc.z, sh.z); val.w = fmaf(val.w, sc.w, sh.w);
       }
-      r[v] = val;
+      if (g.p_act == DVAE_ACT_LRELU) {
+        val.x = lrelu(val.x); val.y = lrelu(val.y); val.z = lrelu(val.z); val.w = lrelu(val.w);
+      }
+      r[v] = zero_unless(val, (mask >> v) & 1u);
     }
   }
 };
@@ -396,17 +477,22 @@ struct WgradPLoader {
 template <int V4, int R>
 struct WgradQLoader {
   const WgradArgs& g;
-  int c2, dh, dw, kr0;
+  int kr0;
+  int coff;        // (dh*WQ + dw)*C2 + c2
+  int bad_a, bad_b;  // the border row / column on which this tap leaves the frame (-1: never)
   bool col_ok;
+  unsigned mask;
   float4 sc, sh;
   __device__ __forceinline__ WgradQLoader(const WgradArgs& g_, int64_t n0) : g(g_) {
-    const int64_t col = n0 + 4 * (threadIdx.x % (R / 4));
+    const int col = (int)n0 + 4 * (threadIdx.x % (R / 4));
     kr0 = threadIdx.x / (R / 4);
     col_ok = col < g.NC;
-    const int tap = (int)(col / g.C2);
-    c2 = (int)(col - (int64_t)tap * g.C2);
-    dh = (tap >> 2) - 1;
-    dw = (tap & 3) - 1;
+    const int tp = col / g.C2;
+    const int c2 = col - tp * g.C2;
+    const int dh = (tp >> 2) - 1, dw = (tp & 3) - 1;
+    coff = (dh * 2 * g.Ws + dw) * g.C2 + c2;
+    bad_a = dh < 0 ? 0 : (dh == 2 ? g.Hs - 1 : -1);
+    bad_b = dw < 0 ? 0 : (dw == 2 ? g.Ws - 1 : -1);
     sc = make_float4(1.f, 1.f, 1.f, 1.f);
     sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col_ok && g.q_scale) {
@@ -414,35 +500,38 @@ struct WgradQLoader {
       sh = *reinterpret_cast<const float4*>(g.q_shift + c2);
     }
   }
-  __device__ __forceinline__ void fetch(int kt, float4 (&r)[V4]) const {
-    const int HQ = 2 * g.Hs, WQ = 2 * g.Ws;
+  __device__ __forceinline__ void issue(int kt, float4 (&r)[V4]) {
+    mask = 0;
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      const int64_t m = (int64_t)kt * 32 + kr0 + v * (1024 / R);
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (col_ok && m < g.Mtot) {
-        const int b = (int)(m & ((1 << g.lw) - 1));
-        const int a = (int)((m >> g.lw) & ((1 << g.lh) - 1));
-        const int64_t n = m >> (g.lw + g.lh);
-        const int hi = 2 * a + dh, wi = 2 * b + dw;
-        if (hi >= 0 && hi < HQ && wi >= 0 && wi < WQ) {
-          val = *reinterpret_cast<const float4*>(g.Q + ((n * HQ + hi) * WQ + wi) * g.C2 + c2);
-          if (g.q_scale) {
-            val.x = fmaf(val.x, sc.x, sh.x); val.y = fmaf(val.y, sc.y, sh.y);
-            val.z = fmaf(val.z, sc.z, sh.z); val.w = fmaf(val.w, sc.w, sh.w);
-          }
-          if (g.q_act == DVAE_ACT_LRELU) {
-            val.x = lrelu(val.x); val.y = lrelu(val.y); val.z = lrelu(val.z); val.w = lrelu(val.w);
-          }
-        }
+      const unsigned m = (unsigned)(kt * 32 + v * (1024 / R)) + (unsigned)kr0;
+      const int b = (int)(m & (unsigned)(g.Ws - 1));
+      const int a = (int)((m >> g.lw) & (unsigned)(g.Hs - 1));
+      const bool eok = col_ok && m < (unsigned)g.Mtot && a != bad_a && b != bad_b;
+      const unsigned e = 4u * m - 2u * (unsigned)b;
+      const float* p = eok ? g.Q + ((int64_t)((uint64_t)e * (unsigned)g.C2) + coff) : g.Q;
+      r[v] = *reinterpret_cast<const float4*>(p);
+      mask |= (unsigned)eok << v;
+    }
+  }
+  __device__ __forceinline__ void finish(float4 (&r)[V4]) const {
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      float4 val = r[v];
+      if (g.q_scale) {
+        val.x = fmaf(val.x, sc.x, sh.x); val.y = fmaf(val.y, sc.y, sh.y);
+        val.z = fmaf(val.z, sc.z, sh.z); val.w = fmaf(val.w, sc.w, sh.w);
       }
-      r[v] = val;
+      if (g.q_act == DVAE_ACT_LRELU) {
+        val.x = lrelu(val.x); val.y = lrelu(val.y); val.z = lrelu(val.z); val.w = lrelu(val.w);
+      }
+      r[v] = zero_unless(val, (mask >> v) & 1u);
     }
   }
 };
 
 template <class T>
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs g) {
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * T::STAGE_FLOATS];
   const int64_t m0 = (int64_t)blockIdx.y * T::BM, n0 = (int64_t)blockIdx.x * T::BN;
   const int ktiles = (int)((g.Mtot + 31) / 32);
@@ -622,6 +711,7 @@ extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, cons
                "conv4s2_wgrad: no load-time transform on a single-channel Q");
   DVAE_REQUIRE(!(C2 == 1 && C1 > 16 * WG1_MAX_CB), "conv4s2_wgrad: single-channel Q supports C1 <= %d", 16 * WG1_MAX_CB);
   DVAE_REQUIRE(aligned16(P) && aligned16(Q) && ws != nullptr, "conv4s2_wgrad: P, Q must be 16-byte aligned, ws non-null");
+  DVAE_REQUIRE(N * Hs * Ws < (1LL << 30), "conv4s2_wgrad: more than 2^30 pixels");
   WgradArgs g;
   g.P = P; g.p_scale = p_scale; g.p_shift = p_shift; g.p_act = p_act;
   g.Q = Q; g.q_scale = q_scale; g.q_shift = q_shift; g.q_act = q_act;

@@ -18,7 +18,7 @@ struct GemmArgs {
 };
 
 template <class T, int KIND>
-__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
+__global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * T::STAGE_FLOATS];
   const int64_t m0 = (int64_t)blockIdx.y * T::BM, n0 = (int64_t)blockIdx.x * T::BN;
   const int ktiles = (int)((g.K + 31) / 32);

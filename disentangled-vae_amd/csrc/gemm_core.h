@@ -128,7 +128,11 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[T::TM][T::TN]) {
 }
 
 // Main loop over K tiles [kt_begin, kt_end).  LA / LB provide
-//   void fetch(int kt, float4 (&regs)[V4])   global -> registers for K tile kt (masked, transformed)
+//   void issue(int kt, float4 (&regs)[V4])   start the global loads of K tile kt; branch-free, and
+//                                            nothing in it may depend on a loaded value
+//   void finish(float4 (&regs)[V4])          load-time transform and zero mask, applied just before
+//                                            the registers go to LDS
+// so the loads of tile kt+1 stay in flight for the whole multiply of tile kt.
 template <class T, class LA, class LB>
 __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int kt_begin, int kt_end, float* smem,
                                               f32x16 (&acc)[T::TM][T::TN]) {
@@ -136,8 +140,10 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int kt_begin, int 
   const int wm = wave / T::WGN, wn = wave % T::WGN;
   float4 ra[T::A_V4], rb[T::B_V4];
   if (kt_begin >= kt_end) return;
-  la.fetch(kt_begin, ra);
-  lb.fetch(kt_begin, rb);
+  la.issue(kt_begin, ra);
+  lb.issue(kt_begin, rb);
+  la.finish(ra);
+  lb.finish(rb);
   store_a_tile<T>(smem, ra);
   store_b_tile<T>(smem + T::A_FLOATS, rb);
   __syncthreads();
@@ -145,13 +151,15 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int kt_begin, int 
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const bool more = kt + 1 < kt_end;
     if (more) {
-      la.fetch(kt + 1, ra);
-      lb.fetch(kt + 1, rb);
+      la.issue(kt + 1, ra);
+      lb.issue(kt + 1, rb);
     }
     const float* st = smem + cur * T::STAGE_FLOATS;
     mma_stage<T>(st, st + T::A_FLOATS, acc, wm, wn, lane);
     if (more) {
       float* nx = smem + (cur ^ 1) * T::STAGE_FLOATS;
+      la.finish(ra);
+      lb.finish(rb);
       store_a_tile<T>(nx, ra);
       store_b_tile<T>(nx + T::A_FLOATS, rb);
     }
@@ -179,43 +187,81 @@ __device__ __forceinline__ void for_each_acc(f32x16 (&acc)[T::TM][T::TN], F f) {
 }
 
 // Plain strided-matrix loaders ---------------------------------------------------------------
+// Out-of-range chunks are read from `base` itself (always valid and 16-byte aligned) and zeroed in
+// finish(), which keeps issue() free of branches.
+__device__ __forceinline__ float4 zero_unless(float4 v, bool keep) {
+  return keep ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // KC: tile rows are matrix rows (R of them starting at row0), k along the contiguous dimension.
+// Everything that does not move with the K tile (row pointer, row validity) is set up once.
 template <int V4>
 struct KCLoader {
   const float* base;
-  int64_t ld;
-  int64_t rows, K;
-  int64_t row0;
-  __device__ __forceinline__ void fetch(int kt, float4 (&r)[V4]) const {
+  const float* rowp[V4];
+  int64_t K;
+  int kofs;
+  unsigned rowok, mask;
+  __device__ __forceinline__ KCLoader(const float* base_, int64_t ld, int64_t rows, int64_t K_, int64_t row0)
+      : base(base_), K(K_) {
+    rowok = 0;
+    kofs = 4 * (threadIdx.x & 7);
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
       int row, ch;
       kc_pos(v, row, ch);
       const int64_t gr = row0 + row;
-      const int64_t k = (int64_t)kt * 32 + 4 * ch;
-      r[v] = (gr < rows && k < K) ? *reinterpret_cast<const float4*>(base + gr * ld + k)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = gr < rows;
+      rowp[v] = base + (ok ? gr * ld : 0) + kofs;
+      rowok |= (unsigned)ok << v;
     }
+  }
+  __device__ __forceinline__ void issue(int kt, float4 (&r)[V4]) {
+    const int k0 = kt * 32;
+    mask = (k0 + kofs < K) ? rowok : 0u;
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      const float* p = (mask >> v) & 1u ? rowp[v] + k0 : base;
+      r[v] = *reinterpret_cast<const float4*>(p);
+    }
+  }
+  __device__ __forceinline__ void finish(float4 (&r)[V4]) const {
+#pragma unroll
+    for (int v = 0; v < V4; ++v) r[v] = zero_unless(r[v], (mask >> v) & 1u);
   }
 };
 
 // RC: tile "rows" index the contiguous dimension of memory (R of them starting at col0); k walks
-// the strided dimension.
+// the strided dimension.  256 % (R/4) == 0, so a thread keeps its column for every chunk it loads.
 template <int V4, int R>
 struct RCLoader {
+  static_assert(256 % (R / 4) == 0, "column position must not depend on the chunk number");
   const float* base;
-  int64_t ld;
-  int64_t cols, K;
-  int64_t col0;
-  __device__ __forceinline__ void fetch(int kt, float4 (&r)[V4]) const {
+  const float* colp;
+  int64_t ld, K;
+  int kr0;
+  bool colok;
+  unsigned mask;
+  __device__ __forceinline__ RCLoader(const float* base_, int64_t ld_, int64_t cols, int64_t K_, int64_t col0)
+      : base(base_), ld(ld_), K(K_) {
+    kr0 = threadIdx.x / (R / 4);
+    const int64_t c = col0 + 4 * (threadIdx.x % (R / 4));
+    colok = c < cols;
+    colp = base + (colok ? (int64_t)kr0 * ld + c : 0);
+  }
+  __device__ __forceinline__ void issue(int kt, float4 (&r)[V4]) {
+    mask = 0;
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      int kr, c4;
-      rc_pos<R>(v, kr, c4);
-      const int64_t k = (int64_t)kt * 32 + kr;
-      const int64_t c = col0 + 4 * c4;
-      r[v] = (k < K && c < cols) ? *reinterpret_cast<const float4*>(base + k * ld + c)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int kk = kt * 32 + v * (1024 / R);       // uniform part of the k index
+      const bool ok = colok && kk + kr0 < K;
+      const float* p = ok ? colp + (int64_t)kk * ld : base;
+      r[v] = *reinterpret_cast<const float4*>(p);
+      mask |= (unsigned)ok << v;
     }
+  }
+  __device__ __forceinline__ void finish(float4 (&r)[V4]) const {
+#pragma unroll
+    for (int v = 0; v < V4; ++v) r[v] = zero_unless(r[v], (mask >> v) & 1u);
   }
 };
