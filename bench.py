@@ -247,6 +247,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-table', action='store_true')
     ap.add_argument('--bucket-mb', type=float, default=16.0)
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+                    help='operand precision of the MFMA kernels for the headline number')
+    ap.add_argument('--no-extras', action='store_true', help='skip the inference and bf16-variant measurements')
     ap.add_argument('--graph', type=int, default=-1, help='1: replay a captured hipGraph per step; 0: eager; '
                     '-1: graph on one GPU, eager (overlapped all-reduce) on several')
     args = ap.parse_args()
@@ -269,6 +272,7 @@ def main():
     from hipvae.optim import FusedAdam
     from hipvae.parallel import GradSync
 
+    ops.set_precision(args.precision)
     cfg = load_config(args.config)
     kind = cfg['model']['model_type']
     t = cfg['training']
@@ -306,52 +310,62 @@ def main():
     use_graph = args.mode == 'train' and (args.graph == 1 or (args.graph == -1 and world == 1))
     if use_graph and world > 1:
         raise SystemExit("--graph 1 is single-GPU only for now (the all-reduce is launched from autograd hooks)")
-    if args.mode == 'train':
+
+    def make_train_step():
         model.train()
-        step = train_step
-        if use_graph:
-            from hipvae.graph import GraphedTrainStep
-            gstep = GraphedTrainStep(model, opt, lambda m, v: loss_call(kind, L, m(v), v, t, beta), ring[0],
-                                     gradient_clip=t['gradient_clip'])
-            step = lambda i: gstep(ring[i % len(ring)])
-    else:
-        model.eval()
-        step = infer_step
+        if not use_graph:
+            return train_step
+        from hipvae.graph import GraphedTrainStep
+        gstep = GraphedTrainStep(model, opt, lambda m, v: loss_call(kind, L, m(v), v, t, beta), ring[0],
+                                 gradient_clip=t['gradient_clip'])
+        return lambda i: gstep(ring[i % len(ring)])
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        last = step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+    def measure(step_fn, steps, warmup):
+        """warm-up, then `steps` steps between barrier + synchronize; max over ranks; seconds"""
+        out = None
+        for i in range(warmup):
+            step_fn(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = step_fn(i)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = tt.item()
+        return el, out
+
+    if args.mode == 'train':
+        step = make_train_step()
+    else:
+        model.eval()
+        step = infer_step
+    elapsed, last = measure(step, args.steps, args.warmup)
     value = world * B * args.steps / elapsed
+    prec_label = 'fp32 MFMA' if args.precision == 'fp32' else 'bf16 MFMA operands, fp32 accumulate and storage'
 
     result = {
         'metric': ('training' if args.mode == 'train' else 'inference') +
                   ' clips/sec (20x64x64 Moving MNIST) at 1/2/4/8 MI355X vs host CPU',
         'value': round(value, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
         'config': {'workload': f"{cfg['name']} ({args.config}) {args.mode} step, beta=4, {T}x{size}x{size} clips, "
-                               f"batch {B}/GPU, fp32 MFMA, {'hipGraph replay' if use_graph else 'eager launches'}",
+                               f"batch {B}/GPU, {prec_label}, {'hipGraph replay' if use_graph else 'eager launches'}",
                    'global_batch': B * world, 'params': n_params,
                    'parallelism': f'dp{world}'},
     }
     if args.mode == 'train':
         result['loss'] = round(float(last['total_loss'].item()), 3)
 
-    if rank == 0 and world == 1 and not args.no_kernel_table:
+    if rank == 0 and world == 1 and not args.no_kernel_table and args.precision == 'fp32':
         step = train_step if args.mode == 'train' else infer_step      # kernels are timed on eager launches
         kt = KernelTimer(ops)
         kt.install()
@@ -367,6 +381,23 @@ def main():
                               'ms_per_step': top['ms_per_step']}
         result['kernels'] = [{k: r[k] for k in ('kernel', 'bound', 'achieved', 'unit', 'frac', 'ms_per_step')}
                              for r in rows[:12]]
+    if args.mode == 'train' and not args.no_extras:
+        # the same job's inference rate (eval-mode forward, no_grad) and its bf16-MFMA variant
+        model.eval()
+        el, _ = measure(infer_step, args.steps, min(args.warmup, 3))
+        result['inference'] = {'value': round(world * B * args.steps / el, 2), 'unit': 'clips/s',
+                               'ms_per_step': round(el / args.steps * 1e3, 3),
+                               'workload': f'eval-mode forward (no_grad), batch {B}/GPU, {prec_label}'}
+        model.train()
+        if args.precision == 'fp32':
+            ops.set_precision('bf16')
+            el, out = measure(make_train_step(), args.steps, args.warmup)
+            result['bf16_variant'] = {'value': round(world * B * args.steps / el, 2), 'unit': 'clips/s',
+                                      'ms_per_step': round(el / args.steps * 1e3, 3),
+                                      'loss': round(float(out['total_loss'].item()), 3),
+                                      'workload': 'same training step with bf16 MFMA operands (fp32 accumulate, '
+                                                  'fp32 tensors); not the headline value'}
+            ops.set_precision('fp32')
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == 'train':

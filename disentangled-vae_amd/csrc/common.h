@@ -17,6 +17,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void dvae_set_error(const char* fmt, ...);
 
+// operand precision of the MFMA GEMM / convolution kernels (process-wide switch)
+#define DVAE_PRECISION_F32 0
+#define DVAE_PRECISION_BF16 1
+int dvae_mfma_precision();
+
 #define DVAE_REQUIRE(cond, ...)                 \
   do {                                          \
     if (!(cond)) {                              \

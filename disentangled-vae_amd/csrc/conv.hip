@@ -144,7 +144,7 @@ struct ConvALoader {
       w0[v] = ww;
     }
   }
-  __device__ __forceinline__ void issue(int kt, float4 (&r)[V4]) {
+  __device__ __forceinline__ void issue(int kt, f32x4 (&r)[V4]) {
     const int ch = threadIdx.x & 7;
     mask = 0;
     if (C1) {
@@ -162,7 +162,7 @@ struct ConvALoader {
           t[kw] = *(eok ? p + kw : g.x);
         }
         mask |= bits << (4 * v);
-        r[v] = make_float4(t[0], t[1], t[2], t[3]);
+        r[v] = (f32x4){t[0], t[1], t[2], t[3]};
       }
       return;
     }
@@ -199,11 +199,11 @@ struct ConvALoader {
     for (int v = 0; v < V4; ++v) {
       const bool eok = kok && ((tapmask[v] >> tp) & 1u);
       const float* p = eok ? g.x + (off0[v] + toff) : g.x;
-      r[v] = *reinterpret_cast<const float4*>(p);
+      r[v] = ldg4(p);
       mask |= (unsigned)eok << v;
     }
   }
-  __device__ __forceinline__ void finish(float4 (&r)[V4]) const {
+  __device__ __forceinline__ void finish(f32x4 (&r)[V4]) const {
     if (C1) {
 #pragma unroll
       for (int v = 0; v < V4; ++v) {
@@ -216,7 +216,7 @@ struct ConvALoader {
     }
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      float4 val = r[v];
+      f32x4 val = r[v];
       if (g.in_scale) {
         val.x = fmaf(val.x, sc.x, sh.x); val.y = fmaf(val.y, sc.y, sh.y);
         val.z = fmaf(val.z, sc.z, sh.z); val.w = fmaf(val.w, sc.w, sh.w);
@@ -229,9 +229,9 @@ struct ConvALoader {
   }
 };
 
-template <class T, int MODE, bool C1>
+template <class T, int MODE, bool C1, bool BF>
 __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * T::STAGE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[2 * Core<T, BF>::STAGE];
   // transposed conv: the four sub-pixel phases of one M tile sit in adjacent workgroups, so the input
   // tile they share is fetched from HBM once and re-read through L2
   const int phase = MODE == 1 ? (int)(blockIdx.x & 3) : 0, ph = phase >> 1, pw = phase & 1;
@@ -240,7 +240,6 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
   const int64_t n0 = (int64_t)blockIdx.y * T::BN;
   const int ktiles = (g.K + 31) / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wn = wave % T::WGN, wm = wave / T::WGN;
   const int l31 = lane & 31;
 
   ConvALoader<T::A_V4, MODE, C1> la(g, ph, pw);
@@ -255,7 +254,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
     la.set_tile(m0);
     f32x16 acc[T::TM][T::TN];
     zero_acc<T>(acc);
-    gemm_mainloop<T>(la, lb, 0, ktiles, smem, acc);
+    gemm_mainloop<T, BF>(la, lb, 0, ktiles, smem, acc);
 
     // store raw output
     for_each_acc<T>(acc, [&](int r, int c, float v) {
@@ -317,7 +316,6 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
         g.stats[(part * 2 + 1) * g.Cout + n] = b;
       }
     }
-    (void)wm;
   }
 }
 
@@ -329,12 +327,16 @@ extern "C" int64_t dvae_conv_stat_parts(int64_t M_rows) {
 template <int MODE>
 static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t stream) {
   const bool c1 = g.Cin == 1;
+  const bool bf = dvae_mfma_precision() == DVAE_PRECISION_BF16;
 #define LAUNCH(TILE, C1FLAG)                                                                         \
   {                                                                                                  \
     g.mtiles = (int)ceil_div64(g.M, TILE::BM);                                                       \
     int gx = g.mtiles < CONV_MAX_PARTS ? g.mtiles : CONV_MAX_PARTS;                                  \
     dim3 grid(gx * phases, (unsigned)ceil_div64(g.Cout, TILE::BN), 1);                               \
-    hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG>), grid, dim3(256), 0, stream, g);        \
+    if (bf && !(C1FLAG))                                                                             \
+      hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG, !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
+    else                                                                                             \
+      hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG, false>), grid, dim3(256), 0, stream, g); \
   }
   typedef Tile<128, 128, 2, 2, true, true> T128;
   typedef Tile<128, 64, 4, 1, true, true> T64;
@@ -428,7 +430,7 @@ struct WgradArgs {
 // (channel, filter tap, pixel offset, which border rows the tap leaves the frame on) is computed
 // once; per K tile only the pixel index m moves.  With Hs, Ws powers of two the Q pixel of (m, tap)
 // sits at element ((4m - 2b) + dh*WQ + dw) * C2 of Q, b = m mod Ws.
-template <int V4, int R>
+template <int V4, int R, bool KADJ>
 struct WgradPLoader {
   const WgradArgs& g;
   int c;          // channel of this thread's 4-float chunk
@@ -447,21 +449,21 @@ struct WgradPLoader {
       sh = *reinterpret_cast<const float4*>(g.p_shift + c);
     }
   }
-  __device__ __forceinline__ void issue(int kt, float4 (&r)[V4]) {
+  __device__ __forceinline__ void issue(int kt, f32x4 (&r)[V4]) {
     mask = 0;
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      const unsigned m = (unsigned)(kt * 32 + v * (1024 / R)) + (unsigned)kr0;
+      const unsigned m = (unsigned)(kt * 32) + (unsigned)(KADJ ? V4 * kr0 + v : v * (1024 / R) + kr0);
       const bool eok = col_ok && m < (unsigned)g.Mtot;
       const float* p = eok ? g.P + ((uint64_t)m * (unsigned)g.C1 + (unsigned)c) : g.P;
-      r[v] = *reinterpret_cast<const float4*>(p);
+      r[v] = ldg4(p);
       mask |= (unsigned)eok << v;
     }
   }
-  __device__ __forceinline__ void finish(float4 (&r)[V4]) const {
+  __device__ __forceinline__ void finish(f32x4 (&r)[V4]) const {
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      float4 val = r[v];
+      f32x4 val = r[v];
       if (g.p_scale) {
         val.x = fmaf(val.x, sc.x, sh.x); val.y = fmaf(val.y, sc.y, sh.y);
         val.z = fmaf(val.z, sc.z, sh.z); val.w = fmaf(val.w, sc.w, sh.w);
@@ -474,7 +476,7 @@ struct WgradPLoader {
   }
 };
 
-template <int V4, int R>
+template <int V4, int R, bool KADJ>
 struct WgradQLoader {
   const WgradArgs& g;
   int kr0;
@@ -500,24 +502,24 @@ struct WgradQLoader {
       sh = *reinterpret_cast<const float4*>(g.q_shift + c2);
     }
   }
-  __device__ __forceinline__ void issue(int kt, float4 (&r)[V4]) {
+  __device__ __forceinline__ void issue(int kt, f32x4 (&r)[V4]) {
     mask = 0;
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      const unsigned m = (unsigned)(kt * 32 + v * (1024 / R)) + (unsigned)kr0;
+      const unsigned m = (unsigned)(kt * 32) + (unsigned)(KADJ ? V4 * kr0 + v : v * (1024 / R) + kr0);
       const int b = (int)(m & (unsigned)(g.Ws - 1));
       const int a = (int)((m >> g.lw) & (unsigned)(g.Hs - 1));
       const bool eok = col_ok && m < (unsigned)g.Mtot && a != bad_a && b != bad_b;
       const unsigned e = 4u * m - 2u * (unsigned)b;
       const float* p = eok ? g.Q + ((int64_t)((uint64_t)e * (unsigned)g.C2) + coff) : g.Q;
-      r[v] = *reinterpret_cast<const float4*>(p);
+      r[v] = ldg4(p);
       mask |= (unsigned)eok << v;
     }
   }
-  __device__ __forceinline__ void finish(float4 (&r)[V4]) const {
+  __device__ __forceinline__ void finish(f32x4 (&r)[V4]) const {
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      float4 val = r[v];
+      f32x4 val = r[v];
       if (g.q_scale) {
         val.x = fmaf(val.x, sc.x, sh.x); val.y = fmaf(val.y, sc.y, sh.y);
         val.z = fmaf(val.z, sc.z, sh.z); val.w = fmaf(val.w, sc.w, sh.w);
@@ -530,9 +532,9 @@ struct WgradQLoader {
   }
 };
 
-template <class T>
+template <class T, bool BF>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs g) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * T::STAGE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[2 * Core<T, BF>::STAGE];
   const int64_t m0 = (int64_t)blockIdx.y * T::BM, n0 = (int64_t)blockIdx.x * T::BN;
   const int ktiles = (int)((g.Mtot + 31) / 32);
   const int kt_begin = blockIdx.z * g.ktiles_per_split;
@@ -540,9 +542,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs g) {
   if (kt_end > ktiles) kt_end = ktiles;
   f32x16 acc[T::TM][T::TN];
   zero_acc<T>(acc);
-  WgradPLoader<T::A_V4, T::BM> la(g, m0);
-  WgradQLoader<T::B_V4, T::BN> lb(g, n0);
-  gemm_mainloop<T>(la, lb, kt_begin, kt_end, smem, acc);
+  WgradPLoader<T::A_V4, T::BM, BF> la(g, m0);
+  WgradQLoader<T::B_V4, T::BN, BF> lb(g, n0);
+  gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
   float* dst = g.slab + (int64_t)blockIdx.z * g.C1 * g.NC;
   for_each_acc<T>(acc, [&](int r, int c, float v) {
     const int64_t m = m0 + r, n = n0 + c;
@@ -729,13 +731,21 @@ extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, cons
     else hipLaunchKernelGGL((conv_wgrad_c1_kernel<8, 2>), grid, dim3(256), 0, s, g);
   } else {
     const dim3 grid((unsigned)p.tn, (unsigned)p.tm, (unsigned)p.split);
+    const bool bf = dvae_mfma_precision() == DVAE_PRECISION_BF16;
+#define WG_LAUNCH(TILE)                                                                     \
+  if (bf) hipLaunchKernelGGL((conv_wgrad_kernel<TILE, true>), grid, dim3(256), 0, s, g);     \
+  else hipLaunchKernelGGL((conv_wgrad_kernel<TILE, false>), grid, dim3(256), 0, s, g);
+    typedef Tile<32, 128, 1, 4, false, false> W32;
+    typedef Tile<64, 128, 2, 2, false, false> W64;
+    typedef Tile<128, 128, 2, 2, false, false> W128;
     if (p.bm == 32) {
-      hipLaunchKernelGGL((conv_wgrad_kernel<Tile<32, 128, 1, 4, false, false>>), grid, dim3(256), 0, s, g);
+      WG_LAUNCH(W32)
     } else if (p.bm == 64) {
-      hipLaunchKernelGGL((conv_wgrad_kernel<Tile<64, 128, 2, 2, false, false>>), grid, dim3(256), 0, s, g);
+      WG_LAUNCH(W64)
     } else {
-      hipLaunchKernelGGL((conv_wgrad_kernel<Tile<128, 128, 2, 2, false, false>>), grid, dim3(256), 0, s, g);
+      WG_LAUNCH(W128)
     }
+#undef WG_LAUNCH
   }
   DVAE_LAUNCH_CHECK("conv4s2_wgrad");
   int64_t nb = ceil_div64(C1 * C2 * 16, 256);

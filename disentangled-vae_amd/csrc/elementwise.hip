@@ -16,7 +16,17 @@ void dvae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dvae_last_error(void) { return g_err; }
-extern "C" int dvae_version(void) { return 1; }
+extern "C" int dvae_version(void) { return 2; }
+
+static int g_mfma_precision = DVAE_PRECISION_F32;
+int dvae_mfma_precision() { return g_mfma_precision; }
+extern "C" int dvae_get_mfma_precision(void) { return g_mfma_precision; }
+extern "C" int dvae_set_mfma_precision(int precision) {
+  DVAE_REQUIRE(precision == DVAE_PRECISION_F32 || precision == DVAE_PRECISION_BF16,
+               "set_mfma_precision: unknown precision %d", precision);
+  g_mfma_precision = precision;
+  return 0;
+}
 
 #define ST(s) ((hipStream_t)(s))
 

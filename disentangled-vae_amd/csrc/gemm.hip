@@ -17,9 +17,9 @@ struct GemmArgs {
   int act, accumulate, ktiles_per_split;
 };
 
-template <class T, int KIND>
+template <class T, int KIND, bool BF>
 __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * T::STAGE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[2 * Core<T, BF>::STAGE];
   const int64_t m0 = (int64_t)blockIdx.y * T::BM, n0 = (int64_t)blockIdx.x * T::BN;
   const int ktiles = (int)((g.K + 31) / 32);
   const int kt_begin = blockIdx.z * g.ktiles_per_split;
@@ -30,17 +30,17 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
   zero_acc<T>(acc);
 
   if (KIND == G_NT) {
-    KCLoader<T::A_V4> la{g.A, g.lda, g.M, g.K, m0};
-    KCLoader<T::B_V4> lb{g.B, g.ldb, g.N, g.K, n0};
-    gemm_mainloop<T>(la, lb, kt_begin, kt_end, smem, acc);
+    KCLoader<T::A_V4> la(g.A, g.lda, g.M, g.K, m0);
+    KCLoader<T::B_V4> lb(g.B, g.ldb, g.N, g.K, n0);
+    gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
   } else if (KIND == G_NN) {
-    KCLoader<T::A_V4> la{g.A, g.lda, g.M, g.K, m0};
-    RCLoader<T::B_V4, T::BN> lb{g.B, g.ldb, g.N, g.K, n0};
-    gemm_mainloop<T>(la, lb, kt_begin, kt_end, smem, acc);
+    KCLoader<T::A_V4> la(g.A, g.lda, g.M, g.K, m0);
+    RCLoader<T::B_V4, T::BN, BF> lb(g.B, g.ldb, g.N, g.K, n0);
+    gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
   } else {
-    RCLoader<T::A_V4, T::BM> la{g.A, g.lda, g.M, g.K, m0};
-    RCLoader<T::B_V4, T::BN> lb{g.B, g.ldb, g.N, g.K, n0};
-    gemm_mainloop<T>(la, lb, kt_begin, kt_end, smem, acc);
+    RCLoader<T::A_V4, T::BM, BF> la(g.A, g.lda, g.M, g.K, m0);
+    RCLoader<T::B_V4, T::BN, BF> lb(g.B, g.ldb, g.N, g.K, n0);
+    gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
   }
 
   if (g.slab) {
@@ -123,10 +123,13 @@ static int launch_gemm(const char* name, GemmArgs g, float* ws, hipStream_t stre
   }
   const dim3 grid((unsigned)p.tn, (unsigned)p.tm, (unsigned)p.split);
   constexpr bool AKC = KIND != G_TN, BKC = KIND == G_NT;
+  const bool bf = dvae_mfma_precision() == DVAE_PRECISION_BF16;
   if (p.small_m) {
-    hipLaunchKernelGGL((gemm_kernel<Tile<32, 128, 1, 4, AKC, BKC>, KIND>), grid, dim3(256), 0, stream, g);
+    if (bf) hipLaunchKernelGGL((gemm_kernel<Tile<32, 128, 1, 4, AKC, BKC>, KIND, true>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_kernel<Tile<32, 128, 1, 4, AKC, BKC>, KIND, false>), grid, dim3(256), 0, stream, g);
   } else {
-    hipLaunchKernelGGL((gemm_kernel<Tile<128, 128, 2, 2, AKC, BKC>, KIND>), grid, dim3(256), 0, stream, g);
+    if (bf) hipLaunchKernelGGL((gemm_kernel<Tile<128, 128, 2, 2, AKC, BKC>, KIND, true>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_kernel<Tile<128, 128, 2, 2, AKC, BKC>, KIND, false>), grid, dim3(256), 0, stream, g);
   }
   DVAE_LAUNCH_CHECK(name);
   if (p.split > 1) {

@@ -11,8 +11,22 @@
 // The MFMA sums over k, so any k order works as long as A and B agree: inside each block of eight
 // k values lane half h (lane>>5) owns k = 4h..4h+3, which is what lets a KC operand be fetched with
 // one 16-B LDS read per lane for four consecutive MFMAs.
+//
+// bf16-operand variant (Core<T, true>): the same loaders and the same fp32 accumulators, but the
+// operands are rounded to bf16 (round-to-nearest-even) on their way into LDS and multiplied by
+// v_mfma_f32_32x32x16_bf16.  Both LDS images are then k-contiguous rows of 32 bf16 (+8 pad), read
+// with one 16-B LDS read per lane per MFMA; a row-contiguous operand is transposed in registers,
+// which needs the thread's chunks of one K tile to sit on consecutive k (KADJ loaders).
 #pragma once
 #include "common.h"
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Staging registers are native 4-vectors, not HIP's float4 struct: arrays of the struct that are
+// read component-wise across elements (the bf16 transpose) were left in scratch memory by the compiler.
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 template <int BM_, int BN_, int WGM_, int WGN_, bool AKC_, bool BKC_>
 struct Tile {
@@ -37,42 +51,44 @@ __device__ __forceinline__ void kc_pos(int v, int& row, int& chunk) {
   row = L >> 3;
   chunk = L & 7;
 }
-// position inside an RC tile with R rows: (k row, 4-float chunk of the row index)
-template <int R>
+// position inside an RC tile with R rows: (k row, 4-float chunk of the row index).  Chunk v of a
+// thread sits 1024/R k rows after chunk v-1, or (KADJ) on the next k row.
+template <int R, bool KADJ = false>
 __device__ __forceinline__ void rc_pos(int v, int& kr, int& c4) {
-  const int L = v * 256 + threadIdx.x;
-  kr = L / (R / 4);
-  c4 = L % (R / 4);
+  constexpr int V4 = R / 32;
+  c4 = threadIdx.x % (R / 4);
+  const int kg = threadIdx.x / (R / 4);
+  kr = KADJ ? V4 * kg + v : v * (1024 / R) + kg;
 }
 
 template <class T>
-__device__ __forceinline__ void store_a_tile(float* lds, const float4 (&r)[T::A_V4]) {
+__device__ __forceinline__ void store_a_tile(float* lds, const f32x4 (&r)[T::A_V4]) {
 #pragma unroll
   for (int v = 0; v < T::A_V4; ++v) {
     if (T::AKC) {
       int row, ch;
       kc_pos(v, row, ch);
-      *reinterpret_cast<float4*>(lds + row * T::ALD + 4 * ch) = r[v];
+      *reinterpret_cast<f32x4*>(lds + row * T::ALD + 4 * ch) = r[v];
     } else {
       int kr, c4;
       rc_pos<T::BM>(v, kr, c4);
-      *reinterpret_cast<float4*>(lds + kr * T::ALD + 4 * c4) = r[v];
+      *reinterpret_cast<f32x4*>(lds + kr * T::ALD + 4 * c4) = r[v];
     }
   }
 }
 
 template <class T>
-__device__ __forceinline__ void store_b_tile(float* lds, const float4 (&r)[T::B_V4]) {
+__device__ __forceinline__ void store_b_tile(float* lds, const f32x4 (&r)[T::B_V4]) {
 #pragma unroll
   for (int v = 0; v < T::B_V4; ++v) {
     if (T::BKC) {
       int row, ch;
       kc_pos(v, row, ch);
-      *reinterpret_cast<float4*>(lds + row * T::BLD + 4 * ch) = r[v];
+      *reinterpret_cast<f32x4*>(lds + row * T::BLD + 4 * ch) = r[v];
     } else {
       int kr, c4;
       rc_pos<T::BN>(v, kr, c4);
-      *reinterpret_cast<float4*>(lds + kr * T::BLD + 4 * c4) = r[v];
+      *reinterpret_cast<f32x4*>(lds + kr * T::BLD + 4 * c4) = r[v];
     }
   }
 }
@@ -127,25 +143,144 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[T::TM][T::TN]) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 }
 
+// ---- bf16-operand staging ------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  const bf16x2 b = __builtin_convertvector(v, bf16x2);   // v_cvt_pk_bf16_f32, round to nearest even
+  uint32_t u;
+  __builtin_memcpy(&u, &b, 4);
+  return u;
+}
+
+#define BF_LD 20   // dwords per LDS row: 32 bf16 + 8 pad = 80 B (16-B reads stay aligned and conflict-free)
+
+// A row holds its 32 bf16 as four 16-B blocks (block b = k 8b..8b+7), stored at block position
+// b ^ ((row >> 4) & 3).  The XOR spreads the transposing stores of a row-contiguous operand (lanes
+// that hold rows 4 apart at the same k) over all banks; readers undo it with the same XOR.
+__device__ __forceinline__ int bf_swz(int row) { return (row >> 4) & 3; }
+
+// one operand tile (ROWS rows x 32 k) into its bf16 image; KC: chunks are 4 consecutive k of one row;
+// RC (KADJ loader order): chunk v holds rows 4*c4..4*c4+3 at k = V4*kg + v
+template <int ROWS, int V4, bool KC>
+__device__ __forceinline__ void store_tile_bf16(uint32_t* lds, const f32x4 (&r)[V4]) {
+  if (KC) {
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      int row, ch;
+      kc_pos(v, row, ch);
+      uint2 w;
+      w.x = pack_bf16(r[v].x, r[v].y);
+      w.y = pack_bf16(r[v].z, r[v].w);
+      *reinterpret_cast<uint2*>(lds + row * BF_LD + 2 * (ch ^ (2 * bf_swz(row)))) = w;
+    }
+  } else {
+    static_assert(KC || V4 == ROWS / 32, "row-contiguous tile: V4 chunks per thread");
+    const int c4 = threadIdx.x % (ROWS / 4), kg = threadIdx.x / (ROWS / 4);
+    const f32x4 r0 = r[0], r1 = r[1 % V4], r2 = r[2 % V4], r3 = r[3 % V4];
+    // component C of the chunks = row 4*c4 + J at the thread's k values
+#define BF_ROW(J, C)                                                                                      \
+  {                                                                                                       \
+    const int row = 4 * c4 + J;                                                                           \
+    const int sw = 2 * bf_swz(row); /* in units of 4 k (8 B) */                                           \
+    if (V4 == 4) { /* k = 4kg..4kg+3: one 8-B quad */                                                     \
+      uint2 w;                                                                                            \
+      w.x = pack_bf16(r0.C, r1.C);                                                                        \
+      w.y = pack_bf16(r2.C, r3.C);                                                                        \
+      *reinterpret_cast<uint2*>(lds + row * BF_LD + 2 * (kg ^ sw)) = w;                                   \
+    } else if (V4 == 2) { /* k = 2kg, 2kg+1: dword kg of the row */                                       \
+      lds[row * BF_LD + 2 * ((kg >> 1) ^ sw) + (kg & 1)] = pack_bf16(r0.C, r1.C);                         \
+    } else { /* k = kg: one halfword */                                                                   \
+      reinterpret_cast<uint16_t*>(lds)[row * (2 * BF_LD) + 4 * ((kg >> 2) ^ sw) + (kg & 3)] =             \
+          (uint16_t)pack_bf16(r0.C, 0.f);                                                                 \
+    }                                                                                                     \
+  }
+    BF_ROW(0, x)
+    BF_ROW(1, y)
+    BF_ROW(2, z)
+    BF_ROW(3, w)
+#undef BF_ROW
+  }
+}
+
+template <class T>
+__device__ __forceinline__ void mma_stage_bf16(const uint32_t* __restrict__ As, const uint32_t* __restrict__ Bs,
+                                               f32x16 (&acc)[T::TM][T::TN], int wm, int wn, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    bf16x8 a[T::TM], b[T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) {
+      const int row = (wm * T::TM + i) * 32 + l31;
+      a[i] = *reinterpret_cast<const bf16x8*>(As + row * BF_LD + 4 * ((2 * q + h) ^ bf_swz(row)));
+    }
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+      const int row = (wn * T::TN + j) * 32 + l31;
+      b[j] = *reinterpret_cast<const bf16x8*>(Bs + row * BF_LD + 4 * ((2 * q + h) ^ bf_swz(row)));
+    }
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+// The two operand precisions behind one interface.  STAGE is in 4-byte units.
+template <class T, bool BF>
+struct Core;
+
+template <class T>
+struct Core<T, false> {
+  static constexpr int STAGE = T::STAGE_FLOATS;
+  static constexpr bool KADJ = false;
+  static __device__ __forceinline__ void store_a(float* st, const f32x4 (&r)[T::A_V4]) { store_a_tile<T>(st, r); }
+  static __device__ __forceinline__ void store_b(float* st, const f32x4 (&r)[T::B_V4]) {
+    store_b_tile<T>(st + T::A_FLOATS, r);
+  }
+  static __device__ __forceinline__ void mma(const float* st, f32x16 (&acc)[T::TM][T::TN], int wm, int wn, int lane) {
+    mma_stage<T>(st, st + T::A_FLOATS, acc, wm, wn, lane);
+  }
+};
+
+template <class T>
+struct Core<T, true> {
+  static constexpr int A_DW = T::BM * BF_LD, B_DW = T::BN * BF_LD;
+  static constexpr int STAGE = A_DW + B_DW;
+  static constexpr bool KADJ = true;
+  static __device__ __forceinline__ void store_a(float* st, const f32x4 (&r)[T::A_V4]) {
+    store_tile_bf16<T::BM, T::A_V4, T::AKC>(reinterpret_cast<uint32_t*>(st), r);
+  }
+  static __device__ __forceinline__ void store_b(float* st, const f32x4 (&r)[T::B_V4]) {
+    store_tile_bf16<T::BN, T::B_V4, T::BKC>(reinterpret_cast<uint32_t*>(st) + A_DW, r);
+  }
+  static __device__ __forceinline__ void mma(const float* st, f32x16 (&acc)[T::TM][T::TN], int wm, int wn, int lane) {
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(st);
+    mma_stage_bf16<T>(s, s + A_DW, acc, wm, wn, lane);
+  }
+};
+
 // Main loop over K tiles [kt_begin, kt_end).  LA / LB provide
 //   void issue(int kt, float4 (&regs)[V4])   start the global loads of K tile kt; branch-free, and
 //                                            nothing in it may depend on a loaded value
 //   void finish(float4 (&regs)[V4])          load-time transform and zero mask, applied just before
 //                                            the registers go to LDS
 // so the loads of tile kt+1 stay in flight for the whole multiply of tile kt.
-template <class T, class LA, class LB>
+template <class T, bool BF, class LA, class LB>
 __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int kt_begin, int kt_end, float* smem,
                                               f32x16 (&acc)[T::TM][T::TN]) {
+  typedef Core<T, BF> C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / T::WGN, wn = wave % T::WGN;
-  float4 ra[T::A_V4], rb[T::B_V4];
+  f32x4 ra[T::A_V4], rb[T::B_V4];
   if (kt_begin >= kt_end) return;
   la.issue(kt_begin, ra);
   lb.issue(kt_begin, rb);
   la.finish(ra);
   lb.finish(rb);
-  store_a_tile<T>(smem, ra);
-  store_b_tile<T>(smem + T::A_FLOATS, rb);
+  C::store_a(smem, ra);
+  C::store_b(smem, rb);
   __syncthreads();
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -154,14 +289,13 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int kt_begin, int 
       la.issue(kt + 1, ra);
       lb.issue(kt + 1, rb);
     }
-    const float* st = smem + cur * T::STAGE_FLOATS;
-    mma_stage<T>(st, st + T::A_FLOATS, acc, wm, wn, lane);
+    C::mma(smem + cur * C::STAGE, acc, wm, wn, lane);
     if (more) {
-      float* nx = smem + (cur ^ 1) * T::STAGE_FLOATS;
+      float* nx = smem + (cur ^ 1) * C::STAGE;
       la.finish(ra);
       lb.finish(rb);
-      store_a_tile<T>(nx, ra);
-      store_b_tile<T>(nx + T::A_FLOATS, rb);
+      C::store_a(nx, ra);
+      C::store_b(nx, rb);
     }
     __syncthreads();
     cur ^= 1;
@@ -189,8 +323,8 @@ __device__ __forceinline__ void for_each_acc(f32x16 (&acc)[T::TM][T::TN], F f) {
 // Plain strided-matrix loaders ---------------------------------------------------------------
 // Out-of-range chunks are read from `base` itself (always valid and 16-byte aligned) and zeroed in
 // finish(), which keeps issue() free of branches.
-__device__ __forceinline__ float4 zero_unless(float4 v, bool keep) {
-  return keep ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+__device__ __forceinline__ f32x4 zero_unless(f32x4 v, bool keep) {
+  return keep ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
 // KC: tile rows are matrix rows (R of them starting at row0), k along the contiguous dimension.
@@ -216,16 +350,16 @@ struct KCLoader {
       rowok |= (unsigned)ok << v;
     }
   }
-  __device__ __forceinline__ void issue(int kt, float4 (&r)[V4]) {
+  __device__ __forceinline__ void issue(int kt, f32x4 (&r)[V4]) {
     const int k0 = kt * 32;
     mask = (k0 + kofs < K) ? rowok : 0u;
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
       const float* p = (mask >> v) & 1u ? rowp[v] + k0 : base;
-      r[v] = *reinterpret_cast<const float4*>(p);
+      r[v] = ldg4(p);
     }
   }
-  __device__ __forceinline__ void finish(float4 (&r)[V4]) const {
+  __device__ __forceinline__ void finish(f32x4 (&r)[V4]) const {
 #pragma unroll
     for (int v = 0; v < V4; ++v) r[v] = zero_unless(r[v], (mask >> v) & 1u);
   }
@@ -233,7 +367,7 @@ struct KCLoader {
 
 // RC: tile "rows" index the contiguous dimension of memory (R of them starting at col0); k walks
 // the strided dimension.  256 % (R/4) == 0, so a thread keeps its column for every chunk it loads.
-template <int V4, int R>
+template <int V4, int R, bool KADJ = false>
 struct RCLoader {
   static_assert(256 % (R / 4) == 0, "column position must not depend on the chunk number");
   const float* base;
@@ -247,20 +381,21 @@ struct RCLoader {
     kr0 = threadIdx.x / (R / 4);
     const int64_t c = col0 + 4 * (threadIdx.x % (R / 4));
     colok = c < cols;
-    colp = base + (colok ? (int64_t)kr0 * ld + c : 0);
+    colp = base + (colok ? (int64_t)((KADJ ? V4 : 1) * kr0) * ld + c : 0);
   }
-  __device__ __forceinline__ void issue(int kt, float4 (&r)[V4]) {
+  __device__ __forceinline__ void issue(int kt, f32x4 (&r)[V4]) {
     mask = 0;
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
-      const int kk = kt * 32 + v * (1024 / R);       // uniform part of the k index
-      const bool ok = colok && kk + kr0 < K;
+      // k index of chunk v = kk + (KADJ ? V4 : 1) * kr0; colp already points at row kr0
+      const int kk = kt * 32 + (KADJ ? v : v * (1024 / R));
+      const bool ok = colok && kk + (KADJ ? V4 : 1) * kr0 < K;
       const float* p = ok ? colp + (int64_t)kk * ld : base;
-      r[v] = *reinterpret_cast<const float4*>(p);
+      r[v] = ldg4(p);
       mask |= (unsigned)ok << v;
     }
   }
-  __device__ __forceinline__ void finish(float4 (&r)[V4]) const {
+  __device__ __forceinline__ void finish(f32x4 (&r)[V4]) const {
 #pragma unroll
     for (int v = 0; v < V4; ++v) r[v] = zero_unless(r[v], (mask >> v) & 1u);
   }

@@ -19,16 +19,18 @@ class GraphedTrainStep:
                  gradient_clip: float = 0.0, warmup: int = 2):
         """loss_of(model, video) -> LossDict (must contain 'total_loss').  The warm-up steps needed
         before capture run on the example batch and are undone afterwards: parameters, buffers and
-        optimiser state are restored in place, so capture does not count as training."""
+        optimiser state are restored in place, so capture does not count as training and may be
+        repeated mid-training (e.g. when beta moves to its next annealing value)."""
         self.model, self.opt, self.loss_of, self.clip = model, optimizer, loss_of, float(gradient_clip)
         self.static_video = example_video.detach().clone()
         tensors = list(model.parameters()) + list(model.buffers())
         snap = [t.detach().clone() for t in tensors]
-        had_state = any(len(optimizer.state[p]) for p in model.parameters() if p in optimizer.state)
-        if had_state:
-            raise RuntimeError("capture the step before the first optimiser step (or after load_state_dict "
-                               "on a fresh optimiser)")
-        optimizer.enable_device_state()
+        # optimiser state as it is now (empty before the first step; mid-training when re-capturing)
+        optimizer._flush_replayed()
+        opt_snap = {p: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                    for p, st in optimizer.state.items()}
+        dyn = optimizer.enable_device_state()
+        dyn_snap = dyn.detach().clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -39,17 +41,20 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.losses = self._step()
-        # undo the warm-up
+        # undo the warm-up steps
         with torch.no_grad():
             for t, s in zip(tensors, snap):
                 t.copy_(s)
-            for st in optimizer.state.values():
-                if 'exp_avg' in st:
-                    st['exp_avg'].zero_()
-                    st['exp_avg_sq'].zero_()
-                    st['step'].zero_()
+            for p, st in optimizer.state.items():
+                old = opt_snap.get(p, {})
+                for k in ('exp_avg', 'exp_avg_sq', 'step'):
+                    if k in st:
+                        if k in old:
+                            st[k].copy_(old[k])
+                        else:
+                            st[k].zero_()
             optimizer._replayed = 0
-            optimizer._dyn[0:1].zero_()
+            dyn.copy_(dyn_snap)
         torch.cuda.synchronize()
 
     def _step(self):

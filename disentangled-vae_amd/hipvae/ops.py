@@ -138,6 +138,21 @@ def indep_bwd(zc, zm, ws, gscale, coef: float):
 
 
 # ---------------------------------------------------------------------------- BatchNorm glue
+PRECISIONS = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
+
+
+def set_precision(name: str) -> None:
+    """Operand precision of the MFMA GEMM / convolution kernels: 'fp32' (default, exact products) or
+    'bf16' (operands rounded to bf16 when staged into LDS, fp32 accumulation, fp32 tensors)."""
+    if name not in PRECISIONS:
+        raise ValueError(f"Unknown precision: {name}. Choose from ['fp32', 'bf16']")
+    check(lib.dvae_set_mfma_precision(PRECISIONS[name]), 'set_mfma_precision')
+
+
+def get_precision() -> str:
+    return 'bf16' if lib.dvae_get_mfma_precision() == 1 else 'fp32'
+
+
 def bn_finalize(partials: Tensor, nparts: int, M: int, gamma, beta, running_mean, running_var, nbt,
                 momentum: float, eps: float):
     """-> (scale, shift, mean, invstd); updates the running buffers in place when given."""

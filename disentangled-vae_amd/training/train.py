@@ -48,6 +48,10 @@ def parse_args(argv=None):
     p.add_argument('--resume', action='store_true')
     p.add_argument('--save-every', type=int, default=10)
     p.add_argument('--visualize-every', type=int, default=5)
+    # not in the reference: operand precision of the MFMA kernels (tensors and checkpoints stay fp32)
+    p.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16'])
+    # not in the reference: replay the training step from a captured hipGraph (one process per node only)
+    p.add_argument('--hip-graph', action='store_true')
     return p.parse_args(argv)
 
 
@@ -83,6 +87,9 @@ def main(argv=None):
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
         dist.init_process_group('nccl')
     set_seed(cfg.data.seed)
+    if args.precision != 'fp32':
+        import hipvae
+        hipvae.set_precision(args.precision)
     if rank == 0:
         print(f"Model type: {cfg.model.model_type}")
         print(f"Data: train {cfg.data.train_size}, val {cfg.data.val_size}, batch {cfg.data.batch_size}"
@@ -98,6 +105,8 @@ def main(argv=None):
         frame_size=cfg.data.frame_size, num_digits=cfg.data.num_digits, num_workers=cfg.data.num_workers,
         seed=cfg.data.seed, rank=rank, world_size=world)
     trainer = create_trainer(cfg, train_loader, val_loader)
+    if args.hip_graph:
+        trainer.use_graph = not trainer.distributed
     history = trainer.train(resume=args.resume)
     if rank == 0:
         print(f"Results saved to: {trainer.results_dir}")

@@ -66,7 +66,9 @@ def beta_for_epoch(t, epoch: int) -> float:
 class Trainer:
 
     def __init__(self, model: nn.Module, config: ExperimentConfig, train_loader, val_loader,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, use_graph: Optional[bool] = None):
+        """use_graph: replay the training step as a captured hipGraph (single process only); default
+        from the environment variable DVAE_HIPGRAPH (off unless it is '1')."""
         self.config = config
         self.train_loader = train_loader
         self.val_loader = val_loader
@@ -97,6 +99,10 @@ class Trainer:
         if self.distributed:
             from hipvae.parallel import GradSync
             self.grad_sync = GradSync(self.model)
+        if use_graph is None:
+            use_graph = os.environ.get('DVAE_HIPGRAPH', '0') == '1'
+        self.use_graph = bool(use_graph) and not self.distributed
+        self._graphs = {}                 # (batch shape, beta) -> GraphedTrainStep
 
         self.checkpoint_dir = os.path.join(t.checkpoint_dir, config.name)
         self.results_dir = os.path.join(t.results_dir, config.name)
@@ -148,6 +154,8 @@ class Trainer:
     # ------------------------------------------------------------------ one optimisation step
     def train_step(self, video: torch.Tensor, beta: float):
         """zero_grad, forward, loss, backward, (all-reduce), clip, Adam (training/trainer.py:192-204)."""
+        if self.use_graph:
+            return self._graphed_step(video, beta)
         if self.grad_sync is not None:
             self.grad_sync.zero_grad()
         else:
@@ -161,6 +169,21 @@ class Trainer:
             self.optimizer.clip_grad_norm_(self.config.training.gradient_clip, fold_into_step=True)
         self.optimizer.step()
         return losses
+
+    def _graphed_step(self, video: torch.Tensor, beta: float):
+        """The same step replayed from a hipGraph captured for this batch shape and beta; beta is a
+        constant of the captured graph, so each annealing value gets its own capture (one per epoch
+        during warm-up) and only the newest two are kept."""
+        from hipvae.graph import GraphedTrainStep
+        key = (tuple(video.shape), float(beta))
+        g = self._graphs.get(key)
+        if g is None:
+            while len(self._graphs) >= 2:
+                self._graphs.pop(next(iter(self._graphs)))
+            g = GraphedTrainStep(self.model, self.optimizer, lambda m, v: self._compute_loss(v, beta)[0], video,
+                                 gradient_clip=self.config.training.gradient_clip)
+            self._graphs[key] = g
+        return g(video)
 
     @staticmethod
     def _unpack(losses, packed_cpu) -> Dict[str, float]:

@@ -33,6 +33,18 @@ typedef void* dvae_stream_t; /* hipStream_t */
 int dvae_version(void);
 const char* dvae_last_error(void);
 
+/* ---- operand precision of the MFMA kernels (dvae_gemm_*, dvae_conv4s2_fwd, dvae_deconv4s2_fwd,
+ *      dvae_conv4s2_wgrad with multi-channel operands).  Process-wide, read when a kernel is launched.
+ *      F32: v_mfma_f32_32x32x2_f32, every product exact (the default; what the 1e-4 parity contract
+ *      is stated for).  BF16: tensors stay fp32 in memory, operands are rounded to bf16 (nearest
+ *      even) as they are staged into LDS and multiplied by v_mfma_f32_32x32x16_bf16 with fp32
+ *      accumulation.  The reference has one precision (fp32, torch defaults); this switch has no
+ *      counterpart there. */
+#define DVAE_PRECISION_F32 0
+#define DVAE_PRECISION_BF16 1
+int dvae_set_mfma_precision(int precision);
+int dvae_get_mfma_precision(void);
+
 /* ---- content / motion split: video.mean(dim=1) (models/encoders.py:251) and
  *      video[:,1:]-video[:,:-1] (models/encoders.py:302-303) in one pass.
  *      video [B,T,P], mean [B,P], diff [B,T-1,P]; P % 4 == 0. */

@@ -5,7 +5,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, 'disentangled-vae_amd')
-for p in (ROOT, PKG):
+for p in (ROOT, PKG, os.path.join(ROOT, 'tests')):
     if p not in sys.path:
         sys.path.insert(0, p)
 

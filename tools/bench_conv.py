@@ -32,8 +32,10 @@ def main():
     ap.add_argument('--frames', type=int, default=5120)
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--only', default='')
+    ap.add_argument('--precision', default='fp32')
     a = ap.parse_args()
     N = a.frames
+    ops.set_precision(a.precision)
     dev = 'cuda'
     # (Cin, Cout, H_in of the transposed conv)
     layers = [(256, 128, 4), (128, 64, 8), (64, 32, 16)]

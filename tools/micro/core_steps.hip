@@ -15,9 +15,9 @@ __global__ void __launch_bounds__(256, 2) core_kernel(const float* A, const floa
   __syncthreads();
   f32x16 acc[T::TM][T::TN];
   zero_acc<T>(acc);
-  float4 ra[T::A_V4], rb[T::B_V4];
-  for (int v = 0; v < T::A_V4; ++v) ra[v] = make_float4(1.f, 2.f, 3.f, 4.f);
-  for (int v = 0; v < T::B_V4; ++v) rb[v] = make_float4(1.f, 2.f, 3.f, 4.f);
+  f32x4 ra[T::A_V4], rb[T::B_V4];
+  for (int v = 0; v < T::A_V4; ++v) ra[v] = (f32x4){1.f, 2.f, 3.f, 4.f};
+  for (int v = 0; v < T::B_V4; ++v) rb[v] = (f32x4){1.f, 2.f, 3.f, 4.f};
   KCLoader<T::A_V4> la(A, K, T::BM, K, 0);
   KCLoader<T::B_V4> lb(B, K, T::BN, K, 0);
   const int ktiles = K / 32;
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256, 2) core2_kernel(const float* A, const flo
   __syncthreads();
   f32x16 acc[T::TM][T::TN];
   zero_acc<T>(acc);
-  float4 ra0[T::A_V4], rb0[T::B_V4], ra1[T::A_V4], rb1[T::B_V4];
+  f32x4 ra0[T::A_V4], rb0[T::B_V4], ra1[T::A_V4], rb1[T::B_V4];
   KCLoader<T::A_V4> la0(A, K, T::BM, K, 0), la1(A, K, T::BM, K, 0);
   KCLoader<T::B_V4> lb0(B, K, T::BN, K, 0), lb1(B, K, T::BN, K, 0);
   const int ktiles = K / 32;
