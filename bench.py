@@ -206,6 +206,23 @@ class KernelTimer:
         return rows
 
 
+def pmc_traffic(label):
+    """HBM bytes per launch of a kernel group from the newest committed counter summary
+    (profiles/*pmc_traffic.json: separate rocprofv3 --pmc passes of this same command; counters cannot
+    be collected inside a timed run).  (None, None) when there is no entry."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_traffic.json')))
+    if not files:
+        return None, None
+    try:
+        entry = json.load(open(files[-1]))['kernels'].get(label)
+    except (OSError, ValueError, KeyError):
+        return None, None
+    if not entry:
+        return None, None
+    return entry['hbm_bytes_per_launch'], os.path.relpath(files[-1], ROOT)
+
+
 # --------------------------------------------------------------------------------------------
 def cpu_baseline(kind, cfg, steps=3, batch=32):
     """The CPU oracle's training step timed on the host cores (bounded sample)."""
@@ -375,8 +392,10 @@ def main():
         rows = kt.summary(nprof)
         kt.remove()
         top = rows[0]
+        traffic, traffic_src = pmc_traffic(top['kernel'])
         result['roofline'] = {'kernel': top['kernel'], 'bound': top['bound'], 'achieved': top['achieved'],
-                              'peak': top['peak'], 'unit': top['unit'], 'frac': top['frac'], 'traffic': None,
+                              'peak': top['peak'], 'unit': top['unit'], 'frac': top['frac'], 'traffic': traffic,
+                              'traffic_source': traffic_src,
                               'avg_launch_us': top['avg_launch_us'], 'launches_per_step': top['launches_per_step'],
                               'ms_per_step': top['ms_per_step']}
         result['kernels'] = [{k: r[k] for k in ('kernel', 'bound', 'achieved', 'unit', 'frac', 'ms_per_step')}

@@ -7,15 +7,35 @@ Counters are summed over dispatches of the same kernel; derived columns:
 """
 import csv
 import glob
+import json
 import os
+import re
 import sys
 from collections import defaultdict
+
+
+def bench_label(name):
+    """the label bench.py's kernel table uses for a kernel symbol (None when it has no single one)"""
+    m = re.match(r'void conv_fwd_kernel<Tile<\d+, (\d+), .*?>, (\d), (true|false), (true|false)>', name)
+    if m:
+        return f"conv_fwd_kernel<T{m.group(1)},{'deconv' if m.group(2) == '1' else 'conv'}" \
+               f"{',c1' if m.group(3) == 'true' else ''}>"
+    m = re.match(r'void conv_wgrad_kernel<Tile<(\d+), (\d+), .*?>, (true|false)>', name)
+    if m:
+        return f'conv_wgrad_kernel<T{m.group(1)}x{m.group(2)}>'
+    m = re.match(r'void gemm_kernel<Tile<.*?>, (\d), (true|false)>', name)
+    if m:
+        return f"gemm_kernel<{('nt', 'nn', 'tn')[int(m.group(1))]}>"
+    m = re.match(r'(?:void )?(\w+)', name)
+    return m.group(1) if m else None
 
 
 def main():
     agg = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(lambda: defaultdict(int))
-    for d in sys.argv[1:]:
+    args = [a for a in sys.argv[1:] if not a.startswith('--json=')]
+    json_out = [a[7:] for a in sys.argv[1:] if a.startswith('--json=')]
+    for d in args:
         for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = r['Kernel_Name']
@@ -33,6 +53,31 @@ def main():
         rows.append((gui, k, n, util, cs.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0.0),
                      None if fetch is None else 2 * fetch * 1024 / n, None if write is None else write * 1024 / n))
     rows.sort(reverse=True)
+    if json_out:
+        table = {}
+        for gui, k, n, util, mops, rd, wr in rows:
+            lab = bench_label(k)
+            if lab is None or rd is None or wr is None:
+                continue
+            e = table.setdefault(lab, {'dispatches': 0, 'hbm_read_bytes': 0.0, 'hbm_write_bytes': 0.0,
+                                       'mfma_busy_frac_weighted': 0.0, 'gui': 0.0})
+            e['dispatches'] += n
+            e['hbm_read_bytes'] += rd * n
+            e['hbm_write_bytes'] += wr * n
+            e['mfma_busy_frac_weighted'] += util * gui
+            e['gui'] += gui
+        out = {}
+        for lab, e in table.items():
+            out[lab] = {'dispatches': e['dispatches'],
+                        'hbm_bytes_per_launch': round((e['hbm_read_bytes'] + e['hbm_write_bytes']) / e['dispatches']),
+                        'hbm_read_bytes_per_launch': round(e['hbm_read_bytes'] / e['dispatches']),
+                        'hbm_write_bytes_per_launch': round(e['hbm_write_bytes'] / e['dispatches']),
+                        'mfma_busy_frac': round(e['mfma_busy_frac_weighted'] / e['gui'], 4) if e['gui'] else None}
+        json.dump({'note': 'rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ/GRBM in separate runs) of '
+                           'bench.py --steps 2 --warmup 1 --graph 0; read bytes = 2 x FETCH_SIZE x 1024 (gfx950 '
+                           'reports half the bytes of wide streaming reads), write bytes = WRITE_SIZE x 1024; '
+                           'per launch = summed over the dispatches of the kernel / their number',
+                   'kernels': out}, open(json_out[0], 'w'), indent=1, sort_keys=True)
     print('| kernel | dispatches | MFMA busy / (active cycles x SIMDs) | f32 MFMA MOPS per dispatch | HBM read B/dispatch (2xFETCH_SIZE) | HBM write B/dispatch |')
     print('|---|---|---|---|---|---|')
     for gui, k, n, util, mops, rd, wr in rows[:40]:
