@@ -66,6 +66,53 @@ extern "C" int dvae_split_mean_diff_f32(const float* video, float* mean, float* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Moving-MNIST renderer: every frame is the max-composite of num_digits 28x28 (digit_size) patches at
+// integer positions that the host simulated (seeded trajectories stay on the host so the draws are
+// those of numpy's generator).  One thread writes four horizontally adjacent pixels; bound by the
+// write of the clip.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+render_clips_kernel(const float* __restrict__ bank, const int* __restrict__ digit_idx, const int* __restrict__ pos,
+                    float4* __restrict__ video, int64_t total4, int T, int nd, int S, int D) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int s4 = S / 4;
+  const int px0 = (int)(i % s4) * 4;
+  const int py = (int)((i / s4) % S);
+  const int64_t frame = i / ((int64_t)s4 * S);          // b*T + t
+  const int64_t b = frame / T;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int d = 0; d < nd; ++d) {
+    const int x = pos[(frame * nd + d) * 2 + 0], y = pos[(frame * nd + d) * 2 + 1];
+    const int dy = py - y;
+    if (dy < 0 || dy >= D) continue;
+    const float* img = bank + ((int64_t)digit_idx[b * nd + d] * D + dy) * D;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int dx = px0 + k - x;
+      if (dx >= 0 && dx < D) v[k] = fmaxf(v[k], img[dx]);
+    }
+  }
+  video[i] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+extern "C" int dvae_render_clips_f32(const float* bank, int64_t bank_size, const int32_t* digit_idx,
+                                     const int32_t* positions, float* video, int64_t B, int64_t T, int64_t num_digits,
+                                     int64_t frame_size, int64_t digit_size, dvae_stream_t stream) {
+  DVAE_REQUIRE(B > 0 && T > 0 && num_digits > 0 && bank_size > 0, "render_clips: empty");
+  DVAE_REQUIRE(frame_size % 4 == 0 && digit_size > 0 && digit_size <= frame_size,
+               "render_clips: frame_size must be a multiple of 4 and >= digit_size (frame %ld digit %ld)",
+               (long)frame_size, (long)digit_size);
+  DVAE_REQUIRE((((uintptr_t)video) & 15) == 0, "render_clips: video must be 16-byte aligned");
+  const int64_t total4 = B * T * frame_size * (frame_size / 4);
+  hipLaunchKernelGGL(render_clips_kernel, dim3((unsigned)ceil_div64(total4, 256)), dim3(256), 0, ST(stream), bank,
+                     (const int*)digit_idx, (const int*)positions, (float4*)video, total4, (int)T, (int)num_digits,
+                     (int)frame_size, (int)digit_size);
+  DVAE_LAUNCH_CHECK("render_clips");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // reconstruction loss
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float recon_elem(float r, float x, int kind) {

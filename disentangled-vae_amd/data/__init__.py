@@ -1,3 +1,3 @@
-from .moving_mnist import MovingMNIST, MovingMNISTWithLabels, get_moving_mnist_dataloaders
+from .moving_mnist import DeviceClipLoader, MovingMNIST, MovingMNISTWithLabels, get_moving_mnist_dataloaders
 
-__all__ = ['MovingMNIST', 'MovingMNISTWithLabels', 'get_moving_mnist_dataloaders']
+__all__ = ['DeviceClipLoader', 'MovingMNIST', 'MovingMNISTWithLabels', 'get_moving_mnist_dataloaders']

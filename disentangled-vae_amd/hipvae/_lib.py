@@ -37,6 +37,7 @@ SIGNATURES = {
     'dvae_reparam_fwd_f32': (I, [P, P, P, P, L, P]),
     'dvae_reparam_bwd_f32': (I, [P, P, P, P, P, L, P]),
     'dvae_kl_fwd_f32': (I, [P, P, P, L, L, F, P]),
+    'dvae_render_clips_f32': (I, [P, L, P, P, P, L, L, L, L, L, P]),
     'dvae_set_mfma_precision': (I, [I]),
     'dvae_get_mfma_precision': (I, []),
     'dvae_kl_bwd_f32': (I, [P, P, P, F, P, P, L, L, F, P]),

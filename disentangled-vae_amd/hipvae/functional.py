@@ -262,6 +262,41 @@ def _empty(*shape, like: Tensor):
     return torch.empty(*shape, dtype=torch.float32, device=like.device)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev: torch.device) -> 'torch.cuda.Stream':
+    """One extra stream per device for work that is independent of what the current stream runs
+    (the second direction of a bidirectional LSTM layer)."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
+class _TwoLanes:
+    """Fork/join around two independent launch sequences: lane 0 stays on the current stream, lane 1
+    runs on the side stream.  Buffers touched inside must have been allocated before entering, and
+    nothing launched inside may use the shared workspace."""
+
+    def __init__(self, like: Tensor, enabled: bool):
+        self.main = torch.cuda.current_stream(like.device)
+        self.side = _side_stream(like.device) if enabled else None
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_stream(self.main)
+        return self
+
+    def lane(self, d: int):
+        return torch.cuda.stream(self.side if (d == 1 and self.side is not None) else self.main)
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+        return False
+
+
 class LSTMEncoder(torch.autograd.Function):
     """nn.LSTM(batch_first, bidirectional, num_layers) from zero state; returns cat of the last
     layer's final hidden state per direction (models/encoders.py:156-173).
@@ -282,17 +317,21 @@ class LSTMEncoder(torch.autograd.Function):
             hseq = _empty(T, B, D * H, like=x)
             cseq = _empty(D, T, B, H, like=x)
             gates = _empty(D, T, B, 4 * H, like=x)
-            for d in range(D):
-                w_ih, w_hh, b_ih, b_hh = [w.detach() for w in weights[(l * D + d) * 4:(l * D + d) * 4 + 4]]
-                xproj = ops.gemm_nt(inp.view(T * B, I), w_ih.contiguous()).view(T, B, 4 * H)
-                order = range(T - 1, -1, -1) if d == 1 else range(T)
-                prev = None
-                for t in order:
-                    h_prev = None if prev is None else hseq[prev][:, d * H:(d + 1) * H]
-                    c_prev = None if prev is None else cseq[d, prev]
-                    ops.lstm_step_fwd(xproj[t], None, None, h_prev, c_prev, w_hh.contiguous(), b_ih, b_hh,
-                                      gates[d, t], hseq[t][:, d * H:(d + 1) * H], cseq[d, t])
-                    prev = t
+            # input projections of both directions first (they may use the shared split-K workspace),
+            # then the two recurrences side by side: they share nothing but the read-only input
+            ws = [[w.detach() for w in weights[(l * D + d) * 4:(l * D + d) * 4 + 4]] for d in range(D)]
+            xproj = [ops.gemm_nt(inp.view(T * B, I), ws[d][0].contiguous()).view(T, B, 4 * H) for d in range(D)]
+            w_hh = [ws[d][1].contiguous() for d in range(D)]
+            with _TwoLanes(x, D == 2) as lanes:
+                for i in range(T):
+                    for d in range(D):
+                        t = T - 1 - i if d == 1 else i
+                        prev = None if i == 0 else (t + 1 if d == 1 else t - 1)
+                        h_prev = None if prev is None else hseq[prev][:, d * H:(d + 1) * H]
+                        c_prev = None if prev is None else cseq[d, prev]
+                        with lanes.lane(d):
+                            ops.lstm_step_fwd(xproj[d][t], None, None, h_prev, c_prev, w_hh[d], ws[d][2], ws[d][3],
+                                              gates[d, t], hseq[t][:, d * H:(d + 1) * H], cseq[d, t])
             layers.append((inp, hseq, cseq, gates))
             inp = hseq
         last = layers[-1][1]
@@ -321,20 +360,28 @@ class LSTMEncoder(torch.autograd.Function):
                 if D == 2:
                     dh[0][:, H:] += dfinal[:, H:]
             dinp = None
+            # the two directions' recurrences side by side, then the weight-gradient GEMMs in turn
+            dgs = [_empty(T, B, 4 * H, like=dfinal) for _ in range(D)]
+            dcs = [[_empty(B, H, like=dfinal), _empty(B, H, like=dfinal)] for _ in range(D)]
+            w_hhs = [weights[(l * D + d) * 4 + 1].contiguous() for d in range(D)]
+            with _TwoLanes(dfinal, D == 2) as lanes:
+                for i in range(T - 1, -1, -1):                    # walk the recurrences backwards
+                    for d in range(D):
+                        t = T - 1 - i if d == 1 else i
+                        tp = None if i == 0 else (t + 1 if d == 1 else t - 1)
+                        sl = slice(d * H, (d + 1) * H)
+                        dc = dcs[d]
+                        with lanes.lane(d):
+                            ops.lstm_step_bwd_pointwise(dh[t][:, sl], None if i == T - 1 else dc[(i + 1) & 1],
+                                                        gates[d, t], None if tp is None else cseq[d, tp], cseq[d, t],
+                                                        dgs[d][t], dc[i & 1])
+                            if tp is not None:
+                                ops.skinny_gemm_nn(dgs[d][t], w_hhs[d], None, dh[tp][:, sl], True)
             for d in range(D):
                 k = (l * D + d) * 4
-                w_ih, w_hh = weights[k].contiguous(), weights[k + 1].contiguous()
-                dg = _empty(T, B, 4 * H, like=dfinal)
-                dc = [_empty(B, H, like=dfinal), _empty(B, H, like=dfinal)]
-                order = list(range(T - 1, -1, -1)) if d == 1 else list(range(T))
+                w_ih = weights[k].contiguous()
+                dg = dgs[d]
                 sl = slice(d * H, (d + 1) * H)
-                for i in range(T - 1, -1, -1):                # walk the recurrence backwards
-                    t = order[i]
-                    tp = order[i - 1] if i > 0 else None
-                    ops.lstm_step_bwd_pointwise(dh[t][:, sl], None if i == T - 1 else dc[(i + 1) & 1], gates[d, t],
-                                                None if tp is None else cseq[d, tp], cseq[d, t], dg[t], dc[i & 1])
-                    if tp is not None:
-                        ops.skinny_gemm_nn(dg[t], w_hh, None, dh[tp][:, sl], True)
                 dg2 = dg.view(T * B, 4 * H)
                 grads[k] = ops.gemm_tn(dg2, inp.view(T * B, I))                      # dW_ih
                 # dW_hh = sum_t dG_t^T h_prev(t): forward uses h[t-1], reverse uses h[t+1]
@@ -345,7 +392,7 @@ class LSTMEncoder(torch.autograd.Function):
                     else:
                         grads[k + 1] = ops.gemm_tn(dg2[:(T - 1) * B], hs2[B:])
                 else:
-                    grads[k + 1] = torch.zeros_like(w_hh)
+                    grads[k + 1] = torch.zeros_like(w_hhs[d])
                 db = ops.bias_act_bwd(dg2, None, ops.ACT_NONE, True)
                 grads[k + 2] = db
                 grads[k + 3] = db.clone()

@@ -63,6 +63,19 @@ def split_mean_diff(video: Tensor) -> Tuple[Tensor, Tensor]:
     return mean, diff
 
 
+def render_clips(bank: Tensor, digit_idx: Tensor, positions: Tensor, frame_size: int) -> Tensor:
+    """bank [N,D,D] f32, digit_idx [B,nd] int32, positions [B,T,nd,2] int32 (x, y) -> clips [B,T,1,S,S]."""
+    _chk(bank)
+    for t in (digit_idx, positions):
+        if not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous():
+            raise RuntimeError("render_clips: digit_idx and positions must be contiguous int32 tensors on the GPU")
+    B, T, nd, _ = positions.shape
+    video = torch.empty(B, T, 1, frame_size, frame_size, dtype=torch.float32, device=bank.device)
+    check(lib.dvae_render_clips_f32(_p(bank), bank.shape[0], digit_idx.data_ptr(), positions.data_ptr(), _p(video),
+                                    B, T, nd, frame_size, bank.shape[1], _stream()), 'render_clips')
+    return video
+
+
 # ---------------------------------------------------------------------------- losses
 def recon_loss_fwd(recon: Tensor, target: Tensor, kind: int, with_temporal: bool, out: Tensor):
     _chk(recon, target, out)

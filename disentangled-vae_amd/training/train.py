@@ -52,6 +52,8 @@ def parse_args(argv=None):
     p.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16'])
     # not in the reference: replay the training step from a captured hipGraph (one process per node only)
     p.add_argument('--hip-graph', action='store_true')
+    # not in the reference: render the Moving-MNIST frames on the GPU (same clips, no DataLoader workers)
+    p.add_argument('--gpu-render', action='store_true')
     return p.parse_args(argv)
 
 
@@ -103,7 +105,8 @@ def main(argv=None):
         root=cfg.data.root, batch_size=cfg.data.batch_size, train_size=cfg.data.train_size,
         val_size=cfg.data.val_size, test_size=cfg.data.test_size, sequence_length=cfg.data.sequence_length,
         frame_size=cfg.data.frame_size, num_digits=cfg.data.num_digits, num_workers=cfg.data.num_workers,
-        seed=cfg.data.seed, rank=rank, world_size=world)
+        seed=cfg.data.seed, rank=rank, world_size=world,
+        render_device=torch.device('cuda', torch.cuda.current_device()) if args.gpu_render else None)
     trainer = create_trainer(cfg, train_loader, val_loader)
     if args.hip_graph:
         trainer.use_graph = not trainer.distributed

@@ -51,6 +51,16 @@ int dvae_get_mfma_precision(void);
 int dvae_split_mean_diff_f32(const float* video, float* mean, float* diff, int64_t B, int64_t T,
                              int64_t P, dvae_stream_t stream);
 
+/* ---- Moving-MNIST frame rendering (data/moving_mnist.py:130-153, the `_render_frame` max-composite):
+ *      bank [bank_size][digit_size][digit_size] digit images; digit_idx [B][num_digits] int32 indices into
+ *      the bank (the caller guarantees 0 <= idx < bank_size); positions [B][T][num_digits][2] int32 (x, y)
+ *      of each digit's top-left corner per frame, already truncated to integers by the host-side
+ *      trajectory simulation; video [B][T][frame_size][frame_size] out.  Pixels outside the canvas are
+ *      clipped as in the reference. */
+int dvae_render_clips_f32(const float* bank, int64_t bank_size, const int32_t* digit_idx,
+                          const int32_t* positions, float* video, int64_t B, int64_t T, int64_t num_digits,
+                          int64_t frame_size, int64_t digit_size, dvae_stream_t stream);
+
 /* ---- reconstruction loss (models/disentangled_vae.py:246-253,263-268; models/lstm_vae.py:182-189;
  *      models/baseline_vae.py:222-229).  kind 0 = MSE, 1 = BCE with log terms clamped at -100.
  *      out[0] = mean loss per pixel, out[1] = out[0]*T*P, out[2] = temporal-difference MSE * (T-1)*P

@@ -94,6 +94,42 @@ def test_generator_is_bit_exact():
     assert float(batch.min()) >= 0 and float(batch.max()) <= 1
 
 
+def test_simulate_is_the_host_generator_without_rendering():
+    """MovingMNIST.simulate (what the GPU renderer is fed) makes the draws of generate_video: same digit
+    images, same trajectory metadata, and its integer positions re-render to the same frames."""
+    from data.moving_mnist import MovingMNIST
+    from tests.golden.make_golden import synthetic_digit_bank
+    bank = synthetic_digit_bank()
+    for kwargs, seed in ((dict(sequence_length=20, frame_size=64, num_digits=2), 42),
+                         (dict(sequence_length=7, frame_size=128, num_digits=3), 0),
+                         (dict(sequence_length=40, frame_size=32, num_digits=1), 7)):
+        ds = MovingMNIST(num_videos=16, seed=seed, deterministic=True, digit_bank=bank, **kwargs)
+        for idx in (0, 3, 15):
+            video, meta = ds[idx]
+            rng = np.random.RandomState(seed + idx if seed else idx)
+            didx, ipos, meta2 = ds.simulate(rng)
+            assert didx.dtype == np.int32 and ipos.dtype == np.int32
+            assert ipos.shape == (kwargs['sequence_length'], kwargs['num_digits'], 2)
+            assert [int(x) for x in meta2['labels']] == [int(x) for x in meta['labels']]
+            for a, b in zip(meta['position_history'], meta2['position_history']):
+                assert all(np.array_equal(x, y) for x, y in zip(a, b))
+            for t in range(kwargs['sequence_length']):
+                frame = ds._render_frame([bank[i] for i in didx], [ipos[t, i].astype(np.float64)
+                                                                   for i in range(kwargs['num_digits'])])
+                assert np.array_equal(frame, video[t, 0].numpy())
+        # the batched, vectorised form used by the device loader: identical draws and trajectories
+        ids = [0, 3, 15, 7, 8]
+        bidx, bpos, bmeta = ds.simulate_batch(ids, with_meta=True)
+        for j, idx in enumerate(ids):
+            didx, ipos, meta = ds.simulate(np.random.RandomState(seed + idx if seed else idx))
+            assert np.array_equal(bidx[j], didx) and np.array_equal(bpos[j], ipos)
+            assert [int(x) for x in bmeta[j]['labels']] == [int(x) for x in meta['labels']]
+            for name in ('position_history', 'velocity_history'):
+                for a, b in zip(meta[name], bmeta[j][name]):
+                    assert all(np.array_equal(x, y) for x, y in zip(a, b)), name
+        assert ds.simulate_batch(ids, with_meta=False)[2] == [{}] * len(ids)
+
+
 def test_missing_mnist_is_a_clear_error(tmp_path):
     from data.moving_mnist import MovingMNIST
     try:

@@ -452,3 +452,29 @@ def test_grad_norm_clip_adam(ops):
     # no clipping when max_norm <= 0
     ops.grad_norm(dg, 0.0, out)
     assert out[1].item() == 1.0
+
+
+# ------------------------------------------------------------------ Moving-MNIST renderer
+@pytest.mark.parametrize('kwargs,seed', [(dict(sequence_length=20, frame_size=64, num_digits=2), 42),
+                                         (dict(sequence_length=5, frame_size=128, num_digits=3), 0),
+                                         (dict(sequence_length=40, frame_size=32, num_digits=1), 7)])
+def test_device_rendered_batches_are_bit_identical(ops, kwargs, seed):
+    """DeviceClipLoader (trajectories on the host, frames rendered by the kernel) against the host
+    DataLoader over the same dataset, shuffled with the same torch seed: identical index order,
+    bit-identical clips, identical metadata."""
+    from torch.utils.data import DataLoader
+    from data.moving_mnist import DeviceClipLoader, MovingMNIST, _collate_fn
+    from tests.golden.make_golden import synthetic_digit_bank
+    bank = synthetic_digit_bank()
+    ds = MovingMNIST(num_videos=23, seed=seed, deterministic=True, digit_bank=bank, **kwargs)
+    torch.manual_seed(3)
+    host = list(DataLoader(ds, batch_size=5, shuffle=True, num_workers=0, collate_fn=_collate_fn))
+    torch.manual_seed(3)
+    dev_batches = list(DeviceClipLoader(ds, batch_size=5, shuffle=True))
+    assert len(host) == len(dev_batches) == 5
+    for (hv, hm), (dv, dm) in zip(host, dev_batches):
+        assert dv.is_cuda and dv.dtype == torch.float32 and dv.shape == hv.shape
+        assert torch.equal(dv.cpu(), hv)
+        for a, b in zip(hm, dm):
+            assert [int(x) for x in a['labels']] == [int(x) for x in b['labels']]
+            assert all(np.array_equal(x, y) for x, y in zip(a['initial_velocities'], b['initial_velocities']))
