@@ -319,9 +319,113 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
   }
 }
 
+// Single-channel input (first encoder layer; data gradient of the final decoder layer): K is only the
+// sixteen filter taps, so the layer is bound by the write of its output.  No LDS staging: every wave
+// takes sixteen consecutive output pixels at a time, gathers their 4x4 input windows straight from the
+// frame (lane = pixel x filter column, one load per filter row) as the B operand of
+// v_mfma_f32_16x16x4_f32, keeps the filter [Cout x 16] in registers as the A operand, and gets four
+// consecutive output channels of one pixel per lane, i.e. 16-B stores that tile each pixel's channel
+// vector.  BatchNorm partial sums are kept per lane and reduced once per workgroup.
+template <int NCB>
+__global__ void __launch_bounds__(256) conv_c1_kernel(ConvArgs g) {
+  __shared__ float red[4][NCB * 16][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, kq = lane >> 4;
+  float wa[NCB][4];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = cb * 16 + i16;
+      wa[cb][r] = co < g.Cout ? g.wp[co * 16 + r * 4 + kq] : 0.f;      // tap (kh = r, kw = kq)
+    }
+  float s1[NCB][4], s2[NCB][4];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[cb][r] = s2[cb][r] = 0.f;
+  const int64_t ngroups = (g.M + 15) / 16;
+  const bool vec_store = (g.Cout & 3) == 0;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t m = grp * 16 + i16;
+    const bool mok = m < g.M;
+    const int b = (int)(m & ((1 << g.lw) - 1));
+    const int a = (int)((m >> g.lw) & ((1 << g.lh) - 1));
+    const int64_t n = m >> (g.lw + g.lh);
+    const float* img = g.x + n * g.H * g.W;
+    const int wi = 2 * b - 1 + kq;
+    const bool wok = mok && wi >= 0 && wi < g.W;
+    float xv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int hi = 2 * a - 1 + r;
+      const bool ok = wok && hi >= 0 && hi < g.H;
+      const float v = *(ok ? img + hi * g.W + wi : g.x);
+      xv[r] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][r], xv[r], acc, 0, 0, 0);
+      // D: row = output channel cb*16 + 4*kq + r, column = pixel i16
+      const int co0 = cb * 16 + 4 * kq;
+      if (mok && co0 < g.Cout) {
+        float* dst = g.y + m * g.Cout + co0;
+        if (vec_store) {
+          *reinterpret_cast<f32x4*>(dst) = acc;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co0 + r < g.Cout) dst[r] = acc[r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s1[cb][r] += acc[r];
+        s2[cb][r] += acc[r] * acc[r];
+      }
+    }
+  }
+  if (g.stats) {
+    // the sixteen lanes with equal kq hold different pixels of the same channels
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a1 = s1[cb][r], a2 = s2[cb][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a1 += __shfl_xor(a1, o);
+          a2 += __shfl_xor(a2, o);
+        }
+        if (i16 == 0) {
+          red[wave][cb * 16 + 4 * kq + r][0] = a1;
+          red[wave][cb * 16 + 4 * kq + r][1] = a2;
+        }
+      }
+    __syncthreads();
+    if (threadIdx.x < NCB * 16 && threadIdx.x < g.Cout) {
+      const int co = threadIdx.x;
+      const float a1 = (red[0][co][0] + red[1][co][0]) + (red[2][co][0] + red[3][co][0]);
+      const float a2 = (red[0][co][1] + red[1][co][1]) + (red[2][co][1] + red[3][co][1]);
+      g.stats[((int64_t)blockIdx.x * 2 + 0) * g.Cout + co] = a1;
+      g.stats[((int64_t)blockIdx.x * 2 + 1) * g.Cout + co] = a2;
+    }
+  }
+}
+
 extern "C" int64_t dvae_conv_stat_parts(int64_t M_rows) {
   (void)M_rows;
   return 4 * CONV_MAX_PARTS;
+}
+
+// number of stat partial rows a forward launch writes
+static int64_t conv_parts_written(int64_t M, int phases) {
+  // all tile shapes use BM = 128
+  int64_t mt = ceil_div64(M, 128);
+  if (mt > CONV_MAX_PARTS) mt = CONV_MAX_PARTS;
+  return mt * phases;
 }
 
 template <int MODE>
@@ -341,7 +445,13 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   typedef Tile<128, 128, 2, 2, true, true> T128;
   typedef Tile<128, 64, 4, 1, true, true> T64;
   typedef Tile<128, 32, 4, 1, true, true> T32;
-  if (c1) {
+  if (c1 && MODE == 0 && g.Cout <= 64 && aligned16(g.y)) {
+    // one partial-statistics row per workgroup, as many rows as the caller sized the buffer for
+    const dim3 grid((unsigned)conv_parts_written(g.M, 1));
+    if (g.Cout <= 16) hipLaunchKernelGGL(conv_c1_kernel<1>, grid, dim3(256), 0, stream, g);
+    else if (g.Cout <= 32) hipLaunchKernelGGL(conv_c1_kernel<2>, grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL(conv_c1_kernel<4>, grid, dim3(256), 0, stream, g);
+  } else if (c1) {
     if (g.Cout > 32) LAUNCH(T64, true) else LAUNCH(T32, true)
   } else if (g.Cout > 64) {
     LAUNCH(T128, false)
@@ -353,14 +463,6 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
 #undef LAUNCH
   DVAE_LAUNCH_CHECK(name);
   return 0;
-}
-
-// number of stat partial rows a forward launch writes
-static int64_t conv_parts_written(int64_t M, int phases) {
-  // all tile shapes use BM = 128
-  int64_t mt = ceil_div64(M, 128);
-  if (mt > CONV_MAX_PARTS) mt = CONV_MAX_PARTS;
-  return mt * phases;
 }
 
 extern "C" int dvae_conv4s2_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
