@@ -203,6 +203,9 @@ struct ConvALoader {
       mask |= (unsigned)eok << v;
     }
   }
+  struct Tag { unsigned mask; float4 sc, sh; };
+  __device__ __forceinline__ Tag tag() const { return Tag{mask, sc, sh}; }
+  __device__ __forceinline__ void set_tag(const Tag& t) { mask = t.mask; sc = t.sc; sh = t.sh; }
   __device__ __forceinline__ void finish(f32x4 (&r)[V4]) const {
     if (C1) {
 #pragma unroll
@@ -562,6 +565,9 @@ struct WgradPLoader {
       mask |= (unsigned)eok << v;
     }
   }
+  struct Tag { unsigned mask; };
+  __device__ __forceinline__ Tag tag() const { return Tag{mask}; }
+  __device__ __forceinline__ void set_tag(const Tag& t) { mask = t.mask; }
   __device__ __forceinline__ void finish(f32x4 (&r)[V4]) const {
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
@@ -618,6 +624,9 @@ struct WgradQLoader {
       mask |= (unsigned)eok << v;
     }
   }
+  struct Tag { unsigned mask; };
+  __device__ __forceinline__ Tag tag() const { return Tag{mask}; }
+  __device__ __forceinline__ void set_tag(const Tag& t) { mask = t.mask; }
   __device__ __forceinline__ void finish(f32x4 (&r)[V4]) const {
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
@@ -646,7 +655,10 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs g) {
   zero_acc<T>(acc);
   WgradPLoader<T::A_V4, T::BM, BF> la(g, m0);
   WgradQLoader<T::B_V4, T::BN, BF> lb(g, n0);
-  gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
+  // the narrow tiles multiply for less time than a load takes: keep two K tiles in flight there
+  // (measured +5 % on the 64x128 tile; the forward kernels lose more to the extra registers)
+  if (T::TM * T::TN <= 2) gemm_mainloop_ahead2<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
+  else gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
   float* dst = g.slab + (int64_t)blockIdx.z * g.C1 * g.NC;
   for_each_acc<T>(acc, [&](int r, int c, float v) {
     const int64_t m = m0 + r, n = n0 + c;

@@ -302,6 +302,67 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int kt_begin, int 
   }
 }
 
+// The same loop with the loads issued two K tiles ahead (two register sets): for tiles whose multiply
+// phase (16-32 MFMAs per wave) is shorter than the memory latency.  Loaders additionally provide
+//   Tag tag() / void set_tag(Tag)    the per-issue state finish() depends on
+template <class T, bool BF, class LA, class LB>
+__device__ __forceinline__ void gemm_mainloop_ahead2(LA& la, LB& lb, int kt_begin, int kt_end, float* smem,
+                                                     f32x16 (&acc)[T::TM][T::TN]) {
+  typedef Core<T, BF> C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / T::WGN, wn = wave % T::WGN;
+  const int n = kt_end - kt_begin;
+  if (n <= 0) return;
+  f32x4 ra0[T::A_V4], rb0[T::B_V4], ra1[T::A_V4], rb1[T::B_V4];
+  typename LA::Tag ta0, ta1;
+  typename LB::Tag tb0, tb1;
+  la.issue(kt_begin, ra0);
+  lb.issue(kt_begin, rb0);
+  ta0 = la.tag();
+  tb0 = lb.tag();
+  ta1 = ta0;
+  tb1 = tb0;
+  if (n > 1) {
+    la.issue(kt_begin + 1, ra1);
+    lb.issue(kt_begin + 1, rb1);
+    ta1 = la.tag();
+    tb1 = lb.tag();
+  }
+  la.set_tag(ta0);
+  lb.set_tag(tb0);
+  la.finish(ra0);
+  lb.finish(rb0);
+  C::store_a(smem, ra0);
+  C::store_b(smem, rb0);
+  __syncthreads();
+  // step i: tile i is in LDS stage i&1, tile i+1 in register set (i+1)&1; set i&1 is free for tile i+2
+#define AHEAD2_STEP(I, RA_FREE, RB_FREE, TA_FREE, TB_FREE, RA_NEXT, RB_NEXT, TA_NEXT, TB_NEXT, SIDX)   \
+  {                                                                                                   \
+    if ((I) + 2 < n) {                                                                                \
+      la.issue(kt_begin + (I) + 2, RA_FREE);                                                          \
+      lb.issue(kt_begin + (I) + 2, RB_FREE);                                                          \
+      TA_FREE = la.tag();                                                                             \
+      TB_FREE = lb.tag();                                                                             \
+    }                                                                                                 \
+    C::mma(smem + (SIDX) * C::STAGE, acc, wm, wn, lane);                                             \
+    if ((I) + 1 < n) {                                                                                \
+      float* nx = smem + ((SIDX) ^ 1) * C::STAGE;                                                     \
+      la.set_tag(TA_NEXT);                                                                            \
+      lb.set_tag(TB_NEXT);                                                                            \
+      la.finish(RA_NEXT);                                                                             \
+      lb.finish(RB_NEXT);                                                                             \
+      C::store_a(nx, RA_NEXT);                                                                        \
+      C::store_b(nx, RB_NEXT);                                                                        \
+    }                                                                                                 \
+    __syncthreads();                                                                                  \
+  }
+  for (int i = 0; i < n; i += 2) {
+    AHEAD2_STEP(i, ra0, rb0, ta0, tb0, ra1, rb1, ta1, tb1, 0)
+    if (i + 1 < n) AHEAD2_STEP(i + 1, ra1, rb1, ta1, tb1, ra0, rb0, ta0, tb0, 1)
+  }
+#undef AHEAD2_STEP
+}
+
 // visit every accumulator element of this lane: f(row_in_tile, col_in_tile, value&)
 template <class T, class F>
 __device__ __forceinline__ void for_each_acc(f32x16 (&acc)[T::TM][T::TN], F f) {
@@ -363,6 +424,10 @@ struct KCLoader {
 #pragma unroll
     for (int v = 0; v < V4; ++v) r[v] = zero_unless(r[v], (mask >> v) & 1u);
   }
+  // what finish() needs from the matching issue(), for main loops that keep two K tiles in flight
+  struct Tag { unsigned mask; };
+  __device__ __forceinline__ Tag tag() const { return Tag{mask}; }
+  __device__ __forceinline__ void set_tag(const Tag& t) { mask = t.mask; }
 };
 
 // RC: tile "rows" index the contiguous dimension of memory (R of them starting at col0); k walks
@@ -399,4 +464,8 @@ struct RCLoader {
 #pragma unroll
     for (int v = 0; v < V4; ++v) r[v] = zero_unless(r[v], (mask >> v) & 1u);
   }
+  // what finish() needs from the matching issue(), for main loops that keep two K tiles in flight
+  struct Tag { unsigned mask; };
+  __device__ __forceinline__ Tag tag() const { return Tag{mask}; }
+  __device__ __forceinline__ void set_tag(const Tag& t) { mask = t.mask; }
 };
