@@ -220,3 +220,60 @@ def test_trainer_with_graph_replay_matches_eager(tmp_path):
     assert sorted(eager) == sorted(graph)
     for k in eager:
         np.testing.assert_allclose(graph[k], eager[k], rtol=1e-6, err_msg=k)
+
+
+def test_gradsync_on_rccl_single_rank_equals_plain_step():
+    """The GPU side of GradSync (gradient hooks, side comm stream, RCCL AVG all-reduce, p.grad aliasing
+    flat buckets, clip + fused Adam reading the aliases) on a one-rank RCCL group: averaging over one
+    rank is the identity, so three steps must give exactly the parameters of three plain steps.  (The
+    multi-rank arithmetic is covered by the two-rank gloo test; two ranks cannot share the one GPU.)"""
+    import socket
+    import torch.distributed as dist
+    import models
+    from hipvae import losses, rng
+    from hipvae.optim import FusedAdam
+    from hipvae.parallel import GradSync
+    cfg = dict(content_dim=8, motion_dim=8, content_channels=[4, 8, 16, 32], motion_channels=[4, 8],
+               decoder_channels=[32, 16, 8, 4], content_feature_dim=32, motion_feature_dim=32, lstm_hidden=16,
+               lstm_layers=1, bidirectional=True, sequence_length=6)
+    batches = [synthetic_clips(4, 6, 90 + i).cuda() for i in range(3)]
+
+    def run(use_sync):
+        torch.manual_seed(21)
+        m = models.DisentangledVAE(**cfg).cuda().train()
+        opt = FusedAdam(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        sync = GradSync(m, bucket_mb=0.02) if use_sync else None
+        if sync is not None:
+            assert len(sync.buckets) >= 3
+        for v in batches:
+            if sync is not None:
+                sync.zero_grad()
+            else:
+                opt.zero_grad(set_to_none=True)
+            out = m(v)
+            losses.disentangled_loss(out, v, beta=0.5, recon_loss_type='bce', independence_weight=0.1,
+                                     temporal_weight=0.05)['total_loss'].backward()
+            if sync is not None:
+                sync.finish()
+            opt.clip_grad_norm_(1.0, fold_into_step=True)
+            opt.step()
+        if sync is not None:
+            sync.remove()
+        return {k: v.clone() for k, v in m.state_dict().items()}
+
+    orig = rng.draw_like
+    rng.draw_like = lambda t: torch.zeros_like(t)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        plain = run(False)
+        synced = run(True)
+    finally:
+        dist.destroy_process_group()
+        rng.draw_like = orig
+    for k in plain:
+        assert torch.equal(plain[k], synced[k]), (k, (plain[k].float() - synced[k].float()).abs().max().item())
