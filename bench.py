@@ -105,8 +105,19 @@ class KernelTimer:
         def conv_key(x, sc, sh, act, wp, stats):
             N, H, W, Cin = x.shape
             Cout = wp.shape[0]
+            if Cin == 1:        # sixteen taps deep: bound by the write of the output
+                return "conv_c1_kernel", float(x.numel() * 4 + N * (H // 2) * (W // 2) * Cout * 4), 'byte'
             fl = 2.0 * N * (H // 2) * (W // 2) * Cout * 16 * Cin
-            return f"conv_fwd_kernel<{tile(Cout)},conv{',c1' if Cin == 1 else ''}>", fl, 'flop'
+            return f"conv_fwd_kernel<{tile(Cout)},conv>", fl, 'flop'
+
+        def conv_bn_key(x, wp, bn_y, aff):
+            key, work, unit = conv_key(x, None, None, 0, wp, True)
+            if unit == 'byte':
+                work += float(bn_y.numel() * 4)
+            return key, work, unit
+
+        def deconv_bn_key(x, wp, bn_y, aff):
+            return deconv_key(x, None, None, 0, wp, True)
 
         def deconv_key(x, sc, sh, act, wp, stats):
             N, H, W, Cin = x.shape
@@ -144,7 +155,9 @@ class KernelTimer:
         def split_key(v):
             return "split_mean_diff_kernel", float(v.numel() * 4 * 2), 'byte'
 
-        def bn_bwd_key(du, y, *r):
+        def bn_bwd_key(du, y, sc, sh, mean, invstd, gamma, partials=None):
+            if partials is not None:       # statistics came from the producing kernel: 2 reads + 1 write
+                return "bn_bwd (apply)", float(y.numel() * 4 * 3), 'byte'
             return "bn_bwd (reduce+apply)", float(y.numel() * 4 * 5), 'byte'    # 2 reads + 2 reads + 1 write
 
         def loss_fwd_key(recon, target, *r):
@@ -167,6 +180,8 @@ class KernelTimer:
 
         self._wrap('conv4s2_fwd', conv_key)
         self._wrap('deconv4s2_fwd', deconv_key)
+        self._wrap('conv4s2_dgrad_bnstat', conv_bn_key)
+        self._wrap('deconv4s2_dgrad_bnstat', deconv_bn_key)
         self._wrap('conv4s2_wgrad', wgrad_key)
         self._wrap('gemm_nt', gemm_key('nt'))
         self._wrap('gemm_nn', gemm_key('nn'))

@@ -87,6 +87,15 @@ struct ConvArgs {
   int mtiles;
   int lc;      // log2(Cin) when Cin is a power of two, else -1
   int cin32;   // Cin % 32 == 0: a K tile never straddles two filter taps
+  // BatchNorm-backward statistics instead of forward statistics (bn_y != nullptr): the output v is a
+  // gradient w.r.t. the activation a = lrelu(bn_y*bn_scale + bn_shift) of a tensor bn_y shaped like
+  // the output; the partial rows then hold sum(dz) and sum(dz*xhat), dz = v*lrelu'(.), xhat =
+  // (bn_y - bn_mean)*bn_invstd.  The output itself is written unchanged.
+  const float* bn_y;
+  const float* bn_scale;
+  const float* bn_shift;
+  const float* bn_mean;
+  const float* bn_invstd;
 };
 
 // A operand of the forward implicit GEMMs.  MODE 0: conv (16 taps, input pixel 2*o-1+k);
@@ -232,7 +241,7 @@ struct ConvALoader {
   }
 };
 
-template <class T, int MODE, bool C1, bool BF>
+template <class T, int MODE, bool C1, bool BF, bool BNS>
 __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * Core<T, BF>::STAGE];
   // transposed conv: the four sub-pixel phases of one M tile sit in adjacent workgroups, so the input
@@ -243,6 +252,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
   const int64_t n0 = (int64_t)blockIdx.y * T::BN;
   const int ktiles = (g.K + 31) / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / T::WGN, wn = wave % T::WGN;
   const int l31 = lane & 31;
 
   ConvALoader<T::A_V4, MODE, C1> la(g, ph, pw);
@@ -275,7 +285,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
         g.y[orow * g.Cout + n] = v;
       }
     });
-    if (g.stats) {
+    if (g.stats && !BNS) {
 #pragma unroll
       for (int i = 0; i < T::TM; ++i)
 #pragma unroll
@@ -286,6 +296,41 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
             s1[j] += v;
             s2[j] += v * v;
           }
+    } else if (BNS) {
+      const int h = lane >> 5;
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) {
+        const int64_t n = n0 + (wn * T::TN + j) * 32 + l31;
+        const bool nok = n < g.Cout;
+        const float bsc = nok ? g.bn_scale[n] : 0.f, bsh = nok ? g.bn_shift[n] : 0.f;
+        const float bmu = nok ? g.bn_mean[n] : 0.f, bis = nok ? g.bn_invstd[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i) {
+          float yv[16];
+          bool ok[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + (wm * T::TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            int64_t orow = m;
+            if (MODE == 1) {
+              const int b = (int)(m & ((1 << g.lw) - 1));
+              const int a = (int)((m >> g.lw) & ((1 << g.lh) - 1));
+              const int64_t img = m >> (g.lw + g.lh);
+              orow = (img * (2 * g.H) + (2 * a + ph)) * (2 * g.W) + (2 * b + pw);
+            }
+            ok[r] = nok && m < g.M;
+            yv[r] = ok[r] ? g.bn_y[orow * g.Cout + n] : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float z = fmaf(yv[r], bsc, bsh);
+            const float v = acc[i][j][r];
+            const float dz = ok[r] ? (z > 0.f ? v : v * LRELU_SLOPE) : 0.f;
+            s1[j] += dz;
+            s2[j] += dz * ((yv[r] - bmu) * bis);
+          }
+        }
+      }
     }
   }
 
@@ -329,7 +374,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
 // v_mfma_f32_16x16x4_f32, keeps the filter [Cout x 16] in registers as the A operand, and gets four
 // consecutive output channels of one pixel per lane, i.e. 16-B stores that tile each pixel's channel
 // vector.  BatchNorm partial sums are kept per lane and reduced once per workgroup.
-template <int NCB>
+template <int NCB, bool BNS>
 __global__ void __launch_bounds__(256) conv_c1_kernel(ConvArgs g) {
   __shared__ float red[4][NCB * 16][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -347,6 +392,21 @@ __global__ void __launch_bounds__(256) conv_c1_kernel(ConvArgs g) {
   for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[cb][r] = s2[cb][r] = 0.f;
+  // BatchNorm-backward statistics: per-channel constants of this lane's four channels per block
+  float bsc[NCB][4], bsh[NCB][4], bmu[NCB][4], bis[NCB][4];
+  if (BNS) {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cb * 16 + 4 * kq + r;
+        const bool ok = co < g.Cout;
+        bsc[cb][r] = ok ? g.bn_scale[co] : 0.f;
+        bsh[cb][r] = ok ? g.bn_shift[co] : 0.f;
+        bmu[cb][r] = ok ? g.bn_mean[co] : 0.f;
+        bis[cb][r] = ok ? g.bn_invstd[co] : 0.f;
+      }
+  }
   const int64_t ngroups = (g.M + 15) / 16;
   const bool vec_store = (g.Cout & 3) == 0;
   for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
@@ -383,10 +443,31 @@ __global__ void __launch_bounds__(256) conv_c1_kernel(ConvArgs g) {
             if (co0 + r < g.Cout) dst[r] = acc[r];
         }
       }
+      if (!BNS) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s1[cb][r] += acc[r];
-        s2[cb][r] += acc[r] * acc[r];
+        for (int r = 0; r < 4; ++r) {
+          s1[cb][r] += acc[r];
+          s2[cb][r] += acc[r] * acc[r];
+        }
+      } else if (mok && co0 < g.Cout) {
+        // BatchNorm-backward statistics of the layer whose activation this gradient belongs to
+        float yv[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* yp = g.bn_y + m * g.Cout + co0;
+        if (vec_store) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(yp);
+          yv[0] = t[0]; yv[1] = t[1]; yv[2] = t[2]; yv[3] = t[3];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co0 + r < g.Cout) yv[r] = yp[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float z = fmaf(yv[r], bsc[cb][r], bsh[cb][r]);
+          const float dz = co0 + r < g.Cout ? (z > 0.f ? acc[r] : acc[r] * LRELU_SLOPE) : 0.f;
+          s1[cb][r] += dz;
+          s2[cb][r] += dz * ((yv[r] - bmu[cb][r]) * bis[cb][r]);
+        }
       }
     }
   }
@@ -435,25 +516,39 @@ template <int MODE>
 static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t stream) {
   const bool c1 = g.Cin == 1;
   const bool bf = dvae_mfma_precision() == DVAE_PRECISION_BF16;
+  const bool bns = g.bn_y != nullptr;
 #define LAUNCH(TILE, C1FLAG)                                                                         \
   {                                                                                                  \
     g.mtiles = (int)ceil_div64(g.M, TILE::BM);                                                       \
     int gx = g.mtiles < CONV_MAX_PARTS ? g.mtiles : CONV_MAX_PARTS;                                  \
     dim3 grid(gx * phases, (unsigned)ceil_div64(g.Cout, TILE::BN), 1);                               \
-    if (bf && !(C1FLAG))                                                                             \
-      hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG, !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
+    if (bns && !(C1FLAG)) {                                                                          \
+      if (bf)                                                                                        \
+        hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG, !(C1FLAG), !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
+      else                                                                                           \
+        hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG, false, !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
+    } else if (bf && !(C1FLAG))                                                                      \
+      hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG, !(C1FLAG), false>), grid, dim3(256), 0, stream, g); \
     else                                                                                             \
-      hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG, false>), grid, dim3(256), 0, stream, g); \
+      hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG, false, false>), grid, dim3(256), 0, stream, g); \
   }
   typedef Tile<128, 128, 2, 2, true, true> T128;
   typedef Tile<128, 64, 4, 1, true, true> T64;
   typedef Tile<128, 32, 4, 1, true, true> T32;
-  if (c1 && MODE == 0 && g.Cout <= 64 && aligned16(g.y)) {
+  if (c1 && MODE == 0 && g.Cout <= 64 && aligned16(g.y) && (!bns || aligned16(g.bn_y))) {
     // one partial-statistics row per workgroup, as many rows as the caller sized the buffer for
     const dim3 grid((unsigned)conv_parts_written(g.M, 1));
-    if (g.Cout <= 16) hipLaunchKernelGGL(conv_c1_kernel<1>, grid, dim3(256), 0, stream, g);
-    else if (g.Cout <= 32) hipLaunchKernelGGL(conv_c1_kernel<2>, grid, dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL(conv_c1_kernel<4>, grid, dim3(256), 0, stream, g);
+#define C1_LAUNCH(NCB)                                                                          \
+  if (bns) hipLaunchKernelGGL((conv_c1_kernel<NCB, true>), grid, dim3(256), 0, stream, g);       \
+  else hipLaunchKernelGGL((conv_c1_kernel<NCB, false>), grid, dim3(256), 0, stream, g);
+    if (g.Cout <= 16) {
+      C1_LAUNCH(1)
+    } else if (g.Cout <= 32) {
+      C1_LAUNCH(2)
+    } else {
+      C1_LAUNCH(4)
+    }
+#undef C1_LAUNCH
   } else if (c1) {
     if (g.Cout > 32) LAUNCH(T64, true) else LAUNCH(T32, true)
   } else if (g.Cout > 64) {
@@ -468,17 +563,27 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   return 0;
 }
 
-extern "C" int dvae_conv4s2_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
-                                    const float* wp, float* y, float* stat_partials, int64_t N, int64_t H, int64_t W,
-                                    int64_t Cin, int64_t Cout, dvae_stream_t stream) {
-  DVAE_REQUIRE(N > 0 && Cout > 0, "conv4s2_fwd: empty");
-  DVAE_REQUIRE(is_pow2(H) && is_pow2(W) && H >= 2 && W >= 2, "conv4s2_fwd: H and W must be powers of two >= 2 (H=%ld W=%ld)",
+struct BnBwdStat {   // see ConvArgs::bn_y
+  const float* y;
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+};
+
+static int conv4s2_fwd_impl(const char* name, const float* x, const float* in_scale, const float* in_shift, int in_act,
+                            const float* wp, float* y, float* stat_partials, int64_t N, int64_t H, int64_t W,
+                            int64_t Cin, int64_t Cout, const BnBwdStat& bn, hipStream_t stream) {
+  DVAE_REQUIRE(N > 0 && Cout > 0, "%s: empty", name);
+  DVAE_REQUIRE(is_pow2(H) && is_pow2(W) && H >= 2 && W >= 2, "%s: H and W must be powers of two >= 2 (H=%ld W=%ld)", name,
                (long)H, (long)W);
-  DVAE_REQUIRE(Cin == 1 || Cin % 4 == 0, "conv4s2_fwd: Cin must be 1 or a multiple of 4 (Cin=%ld)", (long)Cin);
+  DVAE_REQUIRE(Cin == 1 || Cin % 4 == 0, "%s: Cin must be 1 or a multiple of 4 (Cin=%ld)", name, (long)Cin);
   DVAE_REQUIRE(!(Cin == 1 && (in_scale != nullptr || in_act != DVAE_ACT_NONE)),
-               "conv4s2_fwd: no load-time transform on single-channel input");
-  DVAE_REQUIRE(aligned16(x) && aligned16(wp), "conv4s2_fwd: x and wp must be 16-byte aligned");
-  DVAE_REQUIRE(N * H * W * Cin < (1LL << 40), "conv4s2_fwd: tensor too large");
+               "%s: no load-time transform on single-channel input", name);
+  DVAE_REQUIRE(aligned16(x) && aligned16(wp), "%s: x and wp must be 16-byte aligned", name);
+  DVAE_REQUIRE(N * H * W * Cin < (1LL << 40), "%s: tensor too large", name);
+  DVAE_REQUIRE(bn.y == nullptr || (stat_partials && bn.scale && bn.shift && bn.mean && bn.invstd),
+               "%s: BatchNorm-backward statistics need the partials buffer and all four per-channel vectors", name);
   ConvArgs g;
   g.x = x; g.in_scale = in_scale; g.in_shift = in_shift; g.wp = wp; g.y = y; g.stats = stat_partials;
   g.in_act = in_act; g.H = (int)H; g.W = (int)W; g.lh = ilog2(H / 2); g.lw = ilog2(W / 2);
@@ -486,16 +591,19 @@ extern "C" int dvae_conv4s2_fwd_f32(const float* x, const float* in_scale, const
   g.M = N * (H / 2) * (W / 2);
   g.lc = is_pow2(Cin) ? ilog2(Cin) : -1;
   g.cin32 = Cin % 32 == 0;
-  return launch_conv_fwd<0>("conv4s2_fwd", g, 1, ST(stream));
+  g.bn_y = bn.y; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_invstd = bn.invstd;
+  return launch_conv_fwd<0>(name, g, 1, stream);
 }
 
-extern "C" int dvae_deconv4s2_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
-                                      const float* wp, float* y, float* stat_partials, int64_t N, int64_t H,
-                                      int64_t W, int64_t Cin, int64_t Cout, dvae_stream_t stream) {
-  DVAE_REQUIRE(N > 0 && Cout > 0, "deconv4s2_fwd: empty");
-  DVAE_REQUIRE(is_pow2(H) && is_pow2(W), "deconv4s2_fwd: H and W must be powers of two (H=%ld W=%ld)", (long)H, (long)W);
-  DVAE_REQUIRE(Cin % 4 == 0, "deconv4s2_fwd: Cin must be a multiple of 4 (Cin=%ld)", (long)Cin);
-  DVAE_REQUIRE(aligned16(x) && aligned16(wp), "deconv4s2_fwd: x and wp must be 16-byte aligned");
+static int deconv4s2_fwd_impl(const char* name, const float* x, const float* in_scale, const float* in_shift,
+                              int in_act, const float* wp, float* y, float* stat_partials, int64_t N, int64_t H,
+                              int64_t W, int64_t Cin, int64_t Cout, const BnBwdStat& bn, hipStream_t stream) {
+  DVAE_REQUIRE(N > 0 && Cout > 0, "%s: empty", name);
+  DVAE_REQUIRE(is_pow2(H) && is_pow2(W), "%s: H and W must be powers of two (H=%ld W=%ld)", name, (long)H, (long)W);
+  DVAE_REQUIRE(Cin % 4 == 0, "%s: Cin must be a multiple of 4 (Cin=%ld)", name, (long)Cin);
+  DVAE_REQUIRE(aligned16(x) && aligned16(wp), "%s: x and wp must be 16-byte aligned", name);
+  DVAE_REQUIRE(bn.y == nullptr || (stat_partials && bn.scale && bn.shift && bn.mean && bn.invstd),
+               "%s: BatchNorm-backward statistics need the partials buffer and all four per-channel vectors", name);
   ConvArgs g;
   g.x = x; g.in_scale = in_scale; g.in_shift = in_shift; g.wp = wp; g.y = y; g.stats = stat_partials;
   g.in_act = in_act; g.H = (int)H; g.W = (int)W; g.lh = ilog2(H); g.lw = ilog2(W);
@@ -503,7 +611,40 @@ extern "C" int dvae_deconv4s2_fwd_f32(const float* x, const float* in_scale, con
   g.M = N * H * W;
   g.lc = is_pow2(Cin) ? ilog2(Cin) : -1;
   g.cin32 = Cin % 32 == 0;
-  return launch_conv_fwd<1>("deconv4s2_fwd", g, 4, ST(stream));
+  g.bn_y = bn.y; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_invstd = bn.invstd;
+  return launch_conv_fwd<1>(name, g, 4, stream);
+}
+
+extern "C" int dvae_conv4s2_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
+                                    const float* wp, float* y, float* stat_partials, int64_t N, int64_t H, int64_t W,
+                                    int64_t Cin, int64_t Cout, dvae_stream_t stream) {
+  return conv4s2_fwd_impl("conv4s2_fwd", x, in_scale, in_shift, in_act, wp, y, stat_partials, N, H, W, Cin, Cout,
+                          BnBwdStat{nullptr, nullptr, nullptr, nullptr, nullptr}, ST(stream));
+}
+
+extern "C" int dvae_deconv4s2_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
+                                      const float* wp, float* y, float* stat_partials, int64_t N, int64_t H,
+                                      int64_t W, int64_t Cin, int64_t Cout, dvae_stream_t stream) {
+  return deconv4s2_fwd_impl("deconv4s2_fwd", x, in_scale, in_shift, in_act, wp, y, stat_partials, N, H, W, Cin, Cout,
+                            BnBwdStat{nullptr, nullptr, nullptr, nullptr, nullptr}, ST(stream));
+}
+
+extern "C" int dvae_conv4s2_dgrad_bnstat_f32(const float* x, const float* wp, float* y, float* stat_partials,
+                                             int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                                             const float* bn_y, const float* bn_scale, const float* bn_shift,
+                                             const float* bn_mean, const float* bn_invstd, dvae_stream_t stream) {
+  DVAE_REQUIRE(bn_y != nullptr, "conv4s2_dgrad_bnstat: bn_y is null");
+  return conv4s2_fwd_impl("conv4s2_dgrad_bnstat", x, nullptr, nullptr, DVAE_ACT_NONE, wp, y, stat_partials, N, H, W,
+                          Cin, Cout, BnBwdStat{bn_y, bn_scale, bn_shift, bn_mean, bn_invstd}, ST(stream));
+}
+
+extern "C" int dvae_deconv4s2_dgrad_bnstat_f32(const float* x, const float* wp, float* y, float* stat_partials,
+                                               int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                                               const float* bn_y, const float* bn_scale, const float* bn_shift,
+                                               const float* bn_mean, const float* bn_invstd, dvae_stream_t stream) {
+  DVAE_REQUIRE(bn_y != nullptr, "deconv4s2_dgrad_bnstat: bn_y is null");
+  return deconv4s2_fwd_impl("deconv4s2_dgrad_bnstat", x, nullptr, nullptr, DVAE_ACT_NONE, wp, y, stat_partials, N, H,
+                            W, Cin, Cout, BnBwdStat{bn_y, bn_scale, bn_shift, bn_mean, bn_invstd}, ST(stream));
 }
 
 // Host helper used by the Python side through dvae_conv_stat_parts is an upper bound; the exact

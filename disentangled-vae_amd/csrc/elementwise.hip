@@ -754,6 +754,25 @@ extern "C" int dvae_bn_bwd_f32(float* du, const float* y, const float* scale, co
   return 0;
 }
 
+extern "C" int dvae_bn_bwd_from_partials_f32(float* du, const float* y, const float* scale, const float* shift,
+                                             const float* mean, const float* invstd, const float* partials,
+                                             int64_t nparts, float* dgamma, float* dbeta, int64_t M, int64_t C,
+                                             dvae_stream_t stream) {
+  DVAE_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && nparts > 0, "bn_bwd_from_partials: need C%%4==0 and partial rows (C=%ld)",
+               (long)C);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), partials, nparts, 2, C, dbeta,
+                     dgamma);
+  DVAE_LAUNCH_CHECK("bn_bwd_finalize");
+  const int64_t total4 = M * C / 4;
+  int64_t nb = ceil_div64(total4, 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), (float4*)du, (const float4*)y,
+                     scale, shift, mean, invstd, (const float*)dbeta, (const float*)dgamma, 1.f / (float)M, total4,
+                     (int)(C / 4));
+  DVAE_LAUNCH_CHECK("bn_bwd_apply");
+  return 0;
+}
+
 extern "C" int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, float* dbias, float* ws, int64_t M,
                                      int64_t N, dvae_stream_t stream) {
   DVAE_REQUIRE(M > 0 && N > 0 && N % 4 == 0, "bias_act_bwd: need N%%4==0 (N=%ld)", (long)N);

@@ -47,6 +47,14 @@ def _bn_affine(stats, nparts, M, gamma, beta, bn: BNState, training: bool):
 
 
 # =================================================================================================
+def _fuse_bn_stats(channels: int) -> bool:
+    """Whether the data-gradient kernel that produces a gradient with `channels` channels should also
+    reduce the BatchNorm-backward statistics of the layer below.  It pays for the wide-and-shallow
+    tensors (the reduction pass it replaces reads two of them from HBM); on the 128-wide tiles the
+    longer epilogue costs more than that pass."""
+    return channels <= 64
+
+
 class EncoderCNN(torch.autograd.Function):
     """CNNEncoder / LightCNNEncoder of the reference (models/encoders.py:11-97)."""
 
@@ -102,15 +110,19 @@ class EncoderCNN(torch.autograd.Function):
         d_fc_w = ops.permute3(d_wperm, (F_out, S, C), (0, 2, 1)).view(F_out, C * S)
         du = ops.gemm_nn(dpre, w_perm).view(ys[-1].shape)        # grad wrt post-activation of last conv
         d_conv, d_gamma, d_beta = [None] * L, [None] * L, [None] * L
+        parts = None                      # BatchNorm-backward statistics reduced by the producer of du
         for l in range(L - 1, -1, -1):
             sc, sh, mean, invstd = affs[l]
-            d_gamma[l], d_beta[l] = ops.bn_bwd(du, ys[l], sc, sh, mean, invstd, ctx.gammas[l])
+            d_gamma[l], d_beta[l] = ops.bn_bwd(du, ys[l], sc, sh, mean, invstd, ctx.gammas[l], parts)
             dy = du                                              # now dL/d(raw conv output)
             if l > 0:
                 psc, psh = affs[l - 1][0], affs[l - 1][1]
                 d_conv[l] = ops.conv4s2_wgrad(dy, None, None, ops.ACT_NONE, ys[l - 1], psc, psh, ops.ACT_LRELU)
                 wpd = ops.pack_deconv_w(conv_w[l])
-                du, _, _ = ops.deconv4s2_fwd(dy, None, None, ops.ACT_NONE, wpd, False)
+                if _fuse_bn_stats(ys[l - 1].shape[-1]):
+                    du, parts = ops.deconv4s2_dgrad_bnstat(dy, wpd, ys[l - 1], affs[l - 1])
+                else:
+                    (du, _, _), parts = ops.deconv4s2_fwd(dy, None, None, ops.ACT_NONE, wpd, False), None
             else:
                 d_conv[0] = ops.conv4s2_wgrad(dy, None, None, ops.ACT_NONE, x, None, None, ops.ACT_NONE)
         return (None, None, None, d_fc_w, d_fc_b, *d_conv, *d_gamma, *d_beta)
@@ -181,12 +193,17 @@ class DecoderCNN(torch.autograd.Function):
         else:
             xin, xsc, xsh, xact = h0.view(N, 4, 4, C0), None, None, ops.ACT_NONE
         d_final_w = ops.conv4s2_wgrad(xin, xsc, xsh, xact, dlogit4, None, None, ops.ACT_NONE)
-        # the [Cin][1][4][4] weight is already the packed [Cout_c=Cin][4][4][Cin_c=1] conv layout
-        du, _, _ = ops.conv4s2_fwd(dlogit4, None, None, ops.ACT_NONE, final_w.contiguous(), False)
+        # the [Cin][1][4][4] weight is already the packed [Cout_c=Cin][4][4][Cin_c=1] conv layout; every
+        # data-gradient kernel also reduces the BatchNorm-backward statistics of the layer below it
+        parts = None
+        if L > 0 and _fuse_bn_stats(ys[-1].shape[-1]):
+            du, parts = ops.conv4s2_dgrad_bnstat(dlogit4, final_w.contiguous(), ys[-1], affs[-1])
+        else:
+            du, _, _ = ops.conv4s2_fwd(dlogit4, None, None, ops.ACT_NONE, final_w.contiguous(), False)
         d_dec, d_gamma, d_beta = [None] * L, [None] * L, [None] * L
         for l in range(L - 1, -1, -1):
             sc, sh, mean, invstd = affs[l]
-            d_gamma[l], d_beta[l] = ops.bn_bwd(du, ys[l], sc, sh, mean, invstd, ctx.gammas[l])
+            d_gamma[l], d_beta[l] = ops.bn_bwd(du, ys[l], sc, sh, mean, invstd, ctx.gammas[l], parts)
             dy = du
             if l > 0:
                 pin, psc, psh, pact = ys[l - 1], affs[l - 1][0], affs[l - 1][1], ops.ACT_LRELU
@@ -194,7 +211,10 @@ class DecoderCNN(torch.autograd.Function):
                 pin, psc, psh, pact = h0.view(N, 4, 4, C0), None, None, ops.ACT_NONE
             d_dec[l] = ops.conv4s2_wgrad(pin, psc, psh, pact, dy, None, None, ops.ACT_NONE)
             wp = ops.pack_conv_w(dec_w[l])        # [Cin_d][4][4][Cout_d]: the adjoint is a plain conv
-            du, _, _ = ops.conv4s2_fwd(dy, None, None, ops.ACT_NONE, wp, False)
+            if l > 0 and _fuse_bn_stats(ys[l - 1].shape[-1]):
+                du, parts = ops.conv4s2_dgrad_bnstat(dy, wp, ys[l - 1], affs[l - 1])
+            else:
+                (du, _, _), parts = ops.conv4s2_fwd(dy, None, None, ops.ACT_NONE, wp, False), None
         dpre = du.view(N, S * C0)                  # grad wrt h0 (post-LeakyReLU), freshly allocated
         d_bperm = ops.bias_act_bwd(dpre, h0, ops.ACT_LRELU, True)
         d_wperm = ops.gemm_tn(dpre, feat)          # [S*C0, Kin]

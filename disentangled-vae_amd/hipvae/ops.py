@@ -197,12 +197,18 @@ def affine_act(x: Tensor, scale, shift, act: int) -> Tensor:
     return out
 
 
-def bn_bwd(du: Tensor, y: Tensor, scale, shift, mean, invstd, gamma):
-    """Overwrites du with dL/dy; returns (dgamma, dbeta)."""
-    _chk(du, y, scale, shift, mean, invstd, gamma)
+def bn_bwd(du: Tensor, y: Tensor, scale, shift, mean, invstd, gamma, partials: Optional[Tensor] = None):
+    """Overwrites du with dL/dy; returns (dgamma, dbeta).  partials: the [rows][2][C] statistics a
+    *_dgrad_bnstat call reduced while it produced du (skips the reduction pass)."""
+    _chk(du, y, scale, shift, mean, invstd, gamma, partials)
     C = y.shape[-1]
     M = y.numel() // C
     dgb = torch.empty(2, C, dtype=torch.float32, device=y.device)
+    if partials is not None:
+        check(lib.dvae_bn_bwd_from_partials_f32(_p(du), _p(y), _p(scale), _p(shift), _p(mean), _p(invstd),
+                                                _p(partials), partials.shape[0], _p(dgb[0]), _p(dgb[1]), M, C,
+                                                _stream()), 'bn_bwd_from_partials')
+        return dgb[0], dgb[1]
     ws = workspace(2 * lib.dvae_colsum_ws_floats(M, C), y.device)
     check(lib.dvae_bn_bwd_f32(_p(du), _p(y), _p(scale), _p(shift), _p(mean), _p(invstd), _p(gamma), _p(dgb[0]),
                               _p(dgb[1]), _p(ws), M, C, _stream()), 'bn_bwd')
@@ -357,6 +363,38 @@ def deconv4s2_fwd(x: Tensor, scale, shift, act: int, wp: Tensor, want_stats: boo
     check(lib.dvae_deconv4s2_fwd_f32(_p(x), _p(scale), _p(shift), act, _p(wp), _p(y), _p(stats), N, H, W, Cin,
                                      Cout, _stream()), 'deconv4s2_fwd')
     return y, stats, nparts
+
+
+def conv4s2_dgrad_bnstat(x: Tensor, wp: Tensor, bn_y: Tensor, bn_aff):
+    """conv4s2_fwd used as a data gradient that also reduces the BatchNorm-backward statistics of the
+    layer it back-propagates into: returns (du, partials [rows,2,Cout]).  bn_aff = (scale, shift, mean,
+    invstd) of that layer's forward pass, bn_y its raw output (shaped like du)."""
+    _chk(x, wp, bn_y, *bn_aff)
+    N, H, W, Cin = x.shape
+    Cout = wp.shape[0]
+    y = torch.empty(N, H // 2, W // 2, Cout, dtype=torch.float32, device=x.device)
+    assert bn_y.shape == y.shape
+    nparts = lib.dvae_conv_stat_parts_written(N * (H // 2) * (W // 2), 1)
+    stats = torch.empty(nparts, 2, Cout, dtype=torch.float32, device=x.device)
+    sc, sh, mean, invstd = bn_aff
+    check(lib.dvae_conv4s2_dgrad_bnstat_f32(_p(x), _p(wp), _p(y), _p(stats), N, H, W, Cin, Cout, _p(bn_y), _p(sc),
+                                            _p(sh), _p(mean), _p(invstd), _stream()), 'conv4s2_dgrad_bnstat')
+    return y, stats
+
+
+def deconv4s2_dgrad_bnstat(x: Tensor, wp: Tensor, bn_y: Tensor, bn_aff):
+    """deconv4s2_fwd used as a data gradient, with the same fused statistics (see conv4s2_dgrad_bnstat)."""
+    _chk(x, wp, bn_y, *bn_aff)
+    N, H, W, Cin = x.shape
+    Cout = wp.shape[1]
+    y = torch.empty(N, 2 * H, 2 * W, Cout, dtype=torch.float32, device=x.device)
+    assert bn_y.shape == y.shape
+    nparts = lib.dvae_conv_stat_parts_written(N * H * W, 4)
+    stats = torch.empty(nparts, 2, Cout, dtype=torch.float32, device=x.device)
+    sc, sh, mean, invstd = bn_aff
+    check(lib.dvae_deconv4s2_dgrad_bnstat_f32(_p(x), _p(wp), _p(y), _p(stats), N, H, W, Cin, Cout, _p(bn_y), _p(sc),
+                                              _p(sh), _p(mean), _p(invstd), _stream()), 'deconv4s2_dgrad_bnstat')
+    return y, stats
 
 
 def conv4s2_wgrad(P: Tensor, p_scale, p_shift, p_act: int, Q: Tensor, q_scale, q_shift, q_act: int) -> Tensor:

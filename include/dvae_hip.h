@@ -121,6 +121,11 @@ int64_t dvae_colsum_ws_floats(int64_t M, int64_t C);
 int dvae_bn_bwd_f32(float* du, const float* y, const float* scale, const float* shift, const float* mean,
                     const float* invstd, const float* gamma, float* dgamma, float* dbeta, float* ws,
                     int64_t M, int64_t C, dvae_stream_t stream);
+/* The same with step 1 done elsewhere: partials[nparts][2][C] rows of (sum dz, sum dz*xhat) as written by
+ * dvae_conv4s2_dgrad_bnstat_f32 / dvae_deconv4s2_dgrad_bnstat_f32 while they produced du. */
+int dvae_bn_bwd_from_partials_f32(float* du, const float* y, const float* scale, const float* shift,
+                                  const float* mean, const float* invstd, const float* partials, int64_t nparts,
+                                  float* dgamma, float* dbeta, int64_t M, int64_t C, dvae_stream_t stream);
 /* Backward of (bias +) activation of a Linear layer: dpre = dout * act'(out) written in place over
  * dout (act NONE leaves it untouched), dbias[n] = sum_m dpre[m][n] (NULL to skip). [M,N], N%4==0. */
 int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, float* dbias, float* ws, int64_t M,
@@ -179,6 +184,21 @@ int dvae_conv4s2_fwd_f32(const float* x, const float* in_scale, const float* in_
 int dvae_deconv4s2_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
                            const float* wp, float* y, float* stat_partials, int64_t N, int64_t H,
                            int64_t W, int64_t Cin, int64_t Cout, dvae_stream_t stream);
+/* The two kernels above used as data gradients inside a conv -> BatchNorm -> LeakyReLU stack (autograd of
+ * models/encoders.py:32-36 and models/decoders.py:40-45): x is dL/d(raw output of the next layer), y
+ * receives du = dL/d(activation of this layer), unchanged; in the same pass the kernel also reduces what
+ * this layer's BatchNorm backward needs, reading the layer's raw output bn_y (shaped like y) and its
+ * folded forward statistics: stat_partials rows hold sum(dz) and sum(dz*xhat) per channel, with
+ * dz = du*lrelu'(bn_y*bn_scale + bn_shift), xhat = (bn_y - bn_mean)*bn_invstd.  Feed them to
+ * dvae_bn_bwd_from_partials_f32.  No load-time transform on x. */
+int dvae_conv4s2_dgrad_bnstat_f32(const float* x, const float* wp, float* y, float* stat_partials, int64_t N,
+                                  int64_t H, int64_t W, int64_t Cin, int64_t Cout, const float* bn_y,
+                                  const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                  const float* bn_invstd, dvae_stream_t stream);
+int dvae_deconv4s2_dgrad_bnstat_f32(const float* x, const float* wp, float* y, float* stat_partials, int64_t N,
+                                    int64_t H, int64_t W, int64_t Cin, int64_t Cout, const float* bn_y,
+                                    const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                    const float* bn_invstd, dvae_stream_t stream);
 /* Weight gradient shared by both layer kinds:
  *   dw[c1][c2][kh][kw] = sum_{n,a,b} P[n,a,b,c1] * Q[n,2a-1+kh,2b-1+kw,c2]
  * P [N,Hs,Ws,C1] is the small-resolution tensor, Q [N,2Hs,2Ws,C2] the large one (Conv2d: P = dY,

@@ -478,3 +478,46 @@ def test_device_rendered_batches_are_bit_identical(ops, kwargs, seed):
         for a, b in zip(hm, dm):
             assert [int(x) for x in a['labels']] == [int(x) for x in b['labels']]
             assert all(np.array_equal(x, y) for x, y in zip(a['initial_velocities'], b['initial_velocities']))
+
+
+# ------------------------------------------------------------------ data gradient + BatchNorm-backward statistics
+@pytest.mark.parametrize('kind,N,H,Cin,Cout', [('conv', 5, 32, 16, 32), ('conv', 3, 64, 1, 16), ('conv', 3, 64, 1, 32),
+                                               ('conv', 2, 8, 128, 256), ('conv', 70, 4, 4, 36),
+                                               ('deconv', 3, 4, 64, 32), ('deconv', 2, 8, 32, 16),
+                                               ('deconv', 6, 4, 256, 128), ('deconv', 70, 4, 4, 36)])
+def test_dgrad_with_fused_bn_backward_statistics(ops, kind, N, H, Cin, Cout):
+    """The data-gradient kernels with the BatchNorm-backward reduction folded into their epilogue: the
+    gradient they write is the plain kernel's, the partial rows sum to sum(dz) and sum(dz*xhat), and
+    bn_bwd fed with them gives what the two-pass bn_bwd gives."""
+    x = rnd(N, Cin, H, H, seed=50)
+    if kind == 'conv':
+        w = rnd(Cout, Cin, 4, 4, seed=51, scale=0.2)
+        wp = ops.pack_conv_w(dev(w))
+        plain, _, _ = ops.conv4s2_fwd(dev(nhwc(x)), None, None, ops.ACT_NONE, wp, False)
+    else:
+        w = rnd(Cin, Cout, 4, 4, seed=51, scale=0.2)
+        wp = ops.pack_deconv_w(dev(w))
+        plain, _, _ = ops.deconv4s2_fwd(dev(nhwc(x)), None, None, ops.ACT_NONE, wp, False)
+    y = rnd(*plain.shape, seed=52)                      # raw output of the layer below, NHWC
+    gamma, beta = 1 + 0.3 * rnd(Cout, seed=53), 0.2 * rnd(Cout, seed=54)
+    mean = y.mean(dim=(0, 1, 2))
+    var = y.var(dim=(0, 1, 2), unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    sc, sh = gamma * invstd, beta - mean * gamma * invstd
+    aff = (dev(sc), dev(sh), dev(mean), dev(invstd))
+    fn = ops.conv4s2_dgrad_bnstat if kind == 'conv' else ops.deconv4s2_dgrad_bnstat
+    du, parts = fn(dev(nhwc(x)), wp, dev(y), aff)
+    assert torch.equal(du, plain)
+    du64 = plain.double().cpu()
+    z = y * sc + sh
+    dz = du64 * torch.where(z > 0, 1.0, 0.2)
+    xhat = (y - mean) * invstd
+    s = parts.double().sum(0).cpu()
+    assert rel_err(s[0], dz.sum(dim=(0, 1, 2))) < 2e-5
+    assert rel_err(s[1], (dz * xhat).sum(dim=(0, 1, 2))) < 2e-5
+    if Cout % 4 == 0:
+        a = du.clone()
+        dg1, db1 = ops.bn_bwd(a, dev(y), *aff, dev(gamma), parts)
+        b = plain.clone()
+        dg2, db2 = ops.bn_bwd(b, dev(y), *aff, dev(gamma))
+        assert rel_err(a, b) < 2e-6 and rel_err(dg1, dg2) < 2e-5 and rel_err(db1, db2) < 2e-5

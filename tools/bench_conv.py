@@ -60,10 +60,26 @@ def main():
             for name, st in (('plain', False), ('stats', True)):
                 t = timeit(lambda: ops.conv4s2_fwd(dy, None, None, 0, wpc, st), a.reps)
                 rows.append((f'conv (dgrad) {Cout}->{Cin} H{2 * H} {name}', t, flops / t / 1e6))
+        if a.only in ('', 'conv', 'bnstat'):
+            ybn = torch.randn(N, H, H, Cin, device=dev)
+            aff = tuple(torch.rand(Cin, device=dev) + 0.5 for _ in range(4))
+            t = timeit(lambda: ops.conv4s2_dgrad_bnstat(dy, wpc, ybn, aff), a.reps)
+            rows.append((f'conv (dgrad) {Cout}->{Cin} H{2 * H} +bn-bwd stats', t, flops / t / 1e6))
         if a.only in ('', 'wgrad'):
             for name, s1, s2, act in (('plain', None, None, 0), ('bn+lrelu on P', sc, sh, 1)):
                 t = timeit(lambda: ops.conv4s2_wgrad(x, s1, s2, act, dy, None, None, 0), a.reps)
                 rows.append((f'wgrad P{Cin} Q{Cout} Hs{H} {name}', t, flops / t / 1e6))
+    if a.only in ('', 'bnstat', 'c1'):
+        # data gradient of the final layer: single-channel input, Cout = 32, write bound
+        dl = torch.randn(N, 64, 64, 1, device=dev)
+        wf = torch.randn(32, 4, 4, 1, device=dev) * 0.1
+        ybn = torch.randn(N, 32, 32, 32, device=dev)
+        aff = tuple(torch.rand(32, device=dev) + 0.5 for _ in range(4))
+        fl = 2.0 * N * 32 * 32 * 16 * 32
+        t = timeit(lambda: ops.conv4s2_fwd(dl, None, None, 0, wf, False), a.reps)
+        rows.append(('conv c1 (final dgrad) 1->32 H64 plain', t, fl / t / 1e6))
+        t = timeit(lambda: ops.conv4s2_dgrad_bnstat(dl, wf, ybn, aff), a.reps)
+        rows.append(('conv c1 (final dgrad) 1->32 H64 +bn-bwd stats', t, fl / t / 1e6))
     for name, t, tf in rows:
         print(f'{name:48s} {t:9.1f} us {tf:7.1f} TFLOP/s  ({tf / 157.3:.3f} of peak)', flush=True)
 
