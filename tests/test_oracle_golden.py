@@ -111,7 +111,7 @@ def test_schedules_match_reference():
             got = [O.beta_schedule(e, c['beta_vae'], c['kl_start_epoch'], c['use_kl_annealing'],
                                    c['warmup_epochs'], c['annealing_type']) for e in range(len(rec['beta']))]
             np.testing.assert_allclose(got, rec['beta'], rtol=1e-12, atol=1e-15)
-    # the JSON configs: values pinned from SURVEY-independent reference run
+    # the JSON configs: values pinned from a run of the reference itself
     d = sched['disentangled_simple.json']
     got = [O.beta_schedule(e, 0.4, 10, True, 40, 'linear') for e in range(100)]
     np.testing.assert_allclose(got, d['beta'], rtol=1e-12, atol=1e-15)

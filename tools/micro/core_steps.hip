@@ -20,19 +20,31 @@ __global__ void __launch_bounds__(256, 2) core_kernel(const float* A, const floa
   for (int v = 0; v < T::B_V4; ++v) rb[v] = (f32x4){1.f, 2.f, 3.f, 4.f};
   KCLoader<T::A_V4> la(A, K, T::BM, K, 0);
   KCLoader<T::B_V4> lb(B, K, T::BN, K, 0);
+  f32x4 xa[T::A_V4], xb[T::B_V4];
+  float sink = 0.f;
   const int ktiles = K / 32;
   int cur = 0, kt = 0;
   for (int it = 0; it < iters; ++it) {
     if (MODE >= 3) {
-      la.issue(kt, ra);
-      lb.issue(kt, rb);
+      la.issue(kt, MODE == 6 || MODE == 7 ? xa : ra);
+      lb.issue(kt, MODE == 6 || MODE == 7 ? xb : rb);
       if (++kt == ktiles) kt = 0;
     }
     const float* st = smem + cur * T::STAGE_FLOATS;
     mma_stage<T>(st, st + T::A_FLOATS, acc, wm, wn, lane);
+    if (MODE == 6) {   // loads issued, consumed only by a cheap reduction after the multiply
+      for (int v = 0; v < T::A_V4; ++v) sink += xa[v].x;
+      for (int v = 0; v < T::B_V4; ++v) sink += xb[v].x;
+    }
+    if (MODE == 7) {   // loads issued and finished, but constants are what goes to LDS
+      la.finish(xa);
+      lb.finish(xb);
+      for (int v = 0; v < T::A_V4; ++v) sink += xa[v].x + xa[v].w;
+      for (int v = 0; v < T::B_V4; ++v) sink += xb[v].x + xb[v].w;
+    }
     if (MODE >= 2) {
       float* nx = smem + (cur ^ 1) * T::STAGE_FLOATS;
-      if (MODE >= 3) {
+      if (MODE >= 3 && MODE < 6) {
         la.finish(ra);
         lb.finish(rb);
       }
@@ -194,6 +206,8 @@ static void all(const char* name, const float* A, const float* B, float* out, in
   run<T, 1>(name, A, B, out, 256 * per_cu, iters, K);
   run<T, 2>(name, A, B, out, 256 * per_cu, iters, K);
   run<T, 3>(name, A, B, out, 256 * per_cu, iters, K);
+  run<T, 6>(name, A, B, out, 256 * per_cu, iters, K);
+  run<T, 7>(name, A, B, out, 256 * per_cu, iters, K);
   if (T::AKC && T::BKC) {
     run2<T, 4>(name, A, B, out, 256 * per_cu, iters, K);
     run2<T, 5>(name, A, B, out, 256 * per_cu, iters, K);
