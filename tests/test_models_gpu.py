@@ -138,21 +138,38 @@ FULL = {
 }
 
 
-@pytest.mark.parametrize('kind', ['disentangled', 'lstm', 'baseline'])
-def test_full_size_step_against_oracle(kind):
-    """The three JSON configurations at their real layer sizes, B=4: HIP path vs the fp64 oracle."""
+# 128x128 frames need one more stride-2 level everywhere (five encoder / decoder levels, three motion
+# levels); the widened channel lists are those of configs/disentangled_128x128x40.json
+FULL['disentangled_128_narrow'] = dict(content_dim=16, motion_dim=16, content_channels=[8, 16, 32, 64, 64],
+                                       motion_channels=[8, 16, 16], decoder_channels=[64, 64, 32, 16, 8],
+                                       content_feature_dim=64, motion_feature_dim=64, lstm_hidden=32, lstm_layers=1,
+                                       bidirectional=True, sequence_length=6)
+FULL['disentangled_128_wide'] = dict(content_dim=128, motion_dim=128, content_channels=[64, 128, 256, 512, 512],
+                                     motion_channels=[32, 64, 64], decoder_channels=[512, 512, 256, 128, 64],
+                                     content_feature_dim=512, motion_feature_dim=512, lstm_hidden=256, lstm_layers=1,
+                                     bidirectional=True, sequence_length=3)
+CASES = [('disentangled', 4, 20, 64), ('lstm', 4, 20, 64), ('baseline', 4, 20, 64),
+         ('disentangled_128_narrow', 2, 6, 128), ('disentangled_128_wide', 4, 3, 128)]
+
+
+@pytest.mark.parametrize('name,B,T,size', CASES)
+def test_full_size_step_against_oracle(name, B, T, size):
+    """The three JSON configurations at their real layer sizes (B=4), and the 128x128 five-level
+    configuration (narrow and at its full widths, short clips): HIP path vs the fp64 oracle."""
     import models
     from hipvae import rng
-    B, T = 4, 20
+    kind = name.split('_')[0]
     torch.manual_seed(0)
-    m = models.get_model(kind, in_channels=1, **FULL[kind])
+    m = models.get_model(kind, in_channels=1, **FULL[name])
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     gen = torch.Generator().manual_seed(1)
-    video = (torch.rand(B, T, 1, 64, 64, generator=gen) > 0.9).float() * torch.rand(B, T, 1, 64, 64, generator=gen)
-    dim = FULL[kind].get('content_dim', FULL[kind].get('latent_dim'))
+    video = (torch.rand(B, T, 1, size, size, generator=gen) > 0.9).float() * torch.rand(B, T, 1, size, size,
+                                                                                         generator=gen)
+    FULLK = FULL[name]
+    dim = FULLK.get('content_dim', FULLK.get('latent_dim'))
     eps = [torch.randn(B, dim, generator=torch.Generator().manual_seed(100 + k)) for k in range(2)]
     tcfg = SETTINGS['tcfg'][kind]
-    layers = FULL[kind].get('lstm_layers', 1)
+    layers = FULLK.get('lstm_layers', 1)
     # oracle, fp64
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     keys = O.trainable_keys(sd64)
@@ -164,6 +181,13 @@ def test_full_size_step_against_oracle(kind):
                            new_stats=ns)
     oloss = O.model_loss(kind, oout, video.double(), 0.4, tcfg)
     ograds = torch.autograd.grad(oloss['total_loss'], [leaves[k] for k in keys])
+    # the same restatement in fp32: how far fp32 arithmetic itself is from fp64 on this problem
+    leaves32 = {k: sd[k].clone().requires_grad_(True) for k in keys}
+    work32 = dict(sd)
+    work32.update(leaves32)
+    oout32 = O.model_forward(kind, work32, video, eps, True, lstm_layers=layers, new_stats={})
+    ograds32 = torch.autograd.grad(O.model_loss(kind, oout32, video, 0.4, tcfg)['total_loss'],
+                                   [leaves32[k] for k in keys])
     # HIP path
     m = m.cuda().train()
     with rng.inject_eps(eps):
@@ -176,9 +200,12 @@ def test_full_size_step_against_oracle(kind):
     for k in ('total_loss', 'recon_loss', 'kl_loss'):
         assert abs(losses[k].item() - oloss[k].item()) <= 1e-4 * abs(oloss[k].item()) + 1e-6, k
     named = dict(m.named_parameters())
-    for k, og in zip(keys, ograds):
+    for k, og, og32 in zip(keys, ograds, ograds32):
         r = rel(named[k].grad.cpu().numpy(), og.numpy())
-        assert r < 5e-4, (k, r)          # fp32 accumulation over K up to 8192 and B*T*H*W up to 327,680 rows
+        own = rel(og32.numpy(), og.numpy())
+        # fp32 accumulation over K up to 8192 and B*T*H*W up to 327,680 rows; with a handful of frames
+        # per BatchNorm batch the fp32 CPU restatement itself strays further, and sets the bar then
+        assert r < max(5e-4, 2 * own), (k, r, own)
     for k, v in ns.items():
         got = m.state_dict()[k].cpu()
         if v.is_floating_point():
