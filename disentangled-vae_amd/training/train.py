@@ -54,6 +54,9 @@ def parse_args(argv=None):
     p.add_argument('--hip-graph', action='store_true')
     # not in the reference: render the Moving-MNIST frames on the GPU (same clips, no DataLoader workers)
     p.add_argument('--gpu-render', action='store_true')
+    # not in the reference: digit images from a .npy file ([N,28,28], uint8 or float in [0,1]) instead of
+    # MNIST, for machines without the dataset
+    p.add_argument('--digit-bank', type=str, default=None)
     return p.parse_args(argv)
 
 
@@ -101,7 +104,13 @@ def main(argv=None):
               f"device {cfg.training.device}")
     from data import get_moving_mnist_dataloaders
     from training.trainer import create_trainer
+    bank = None
+    if args.digit_bank is not None:
+        import numpy as np
+        bank = np.load(args.digit_bank)
+        bank = bank.astype(np.float32) / 255.0 if bank.dtype == np.uint8 else bank.astype(np.float32)
     train_loader, val_loader, _ = get_moving_mnist_dataloaders(
+        digit_bank=bank,
         root=cfg.data.root, batch_size=cfg.data.batch_size, train_size=cfg.data.train_size,
         val_size=cfg.data.val_size, test_size=cfg.data.test_size, sequence_length=cfg.data.sequence_length,
         frame_size=cfg.data.frame_size, num_digits=cfg.data.num_digits, num_workers=cfg.data.num_workers,
