@@ -282,6 +282,9 @@ def main():
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                     help='operand precision of the MFMA kernels for the headline number')
     ap.add_argument('--no-extras', action='store_true', help='skip the inference and bf16-variant measurements')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='initialise the RCCL process group and use the data-parallel step even with one rank '
+                         '(exercises the multi-GPU code path on a single GPU)')
     ap.add_argument('--graph', type=int, default=-1, help='1: replay a captured hipGraph per step; 0: eager; '
                     '-1: graph on one GPU, eager (overlapped all-reduce) on several')
     args = ap.parse_args()
@@ -296,8 +299,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+    use_dp = world > 1 or args.force_dist
+    if use_dp:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     import models
     from hipvae import losses as L, ops
@@ -315,7 +321,7 @@ def main():
     n_params = sum(p.numel() for p in model.parameters())
     opt = FusedAdam(model.parameters(), lr=t['learning_rate'], betas=(t['beta1'], t['beta2']),
                     weight_decay=t['weight_decay'])
-    sync = GradSync(model, bucket_mb=args.bucket_mb) if world > 1 else None
+    sync = GradSync(model, bucket_mb=args.bucket_mb) if use_dp else None
     ring = [synthetic_clips(B, T, size, 1000 * rank + i).to(dev) for i in range(4)]
     beta = 4.0
 
@@ -339,8 +345,8 @@ def main():
         with torch.no_grad():
             return model(ring[i % len(ring)])
 
-    use_graph = args.mode == 'train' and (args.graph == 1 or (args.graph == -1 and world == 1))
-    if use_graph and world > 1:
+    use_graph = args.mode == 'train' and (args.graph == 1 or (args.graph == -1 and not use_dp))
+    if use_graph and use_dp:
         raise SystemExit("--graph 1 is single-GPU only for now (the all-reduce is launched from autograd hooks)")
 
     def make_train_step():
@@ -353,7 +359,7 @@ def main():
         return lambda i: gstep(ring[i % len(ring)])
 
     def barrier():
-        if world > 1:
+        if use_dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -368,7 +374,7 @@ def main():
             out = step_fn(i)
         barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if use_dp:
             tt = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = tt.item()
@@ -432,13 +438,13 @@ def main():
                                       'workload': 'same training step with bf16 MFMA operands (fp32 accumulate, '
                                                   'fp32 tensors); not the headline value'}
             ops.set_precision('fp32')
-    if world > 1:
+    if use_dp:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == 'train':
         result['cpu_baseline'] = cpu_baseline(kind, cfg)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dp:
         dist.barrier()
         dist.destroy_process_group()
 

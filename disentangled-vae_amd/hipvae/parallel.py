@@ -77,12 +77,23 @@ class GradSync:
     # called by autograd once a parameter's gradient for this step is complete
     def _on_grad(self, p: torch.nn.Parameter):
         b, i = self._where[p]
-        b.views[i].copy_(p.grad)
-        p.grad = None                      # the bucket slice becomes the gradient in finish()
         b.got[i] = True
         b.pending -= 1
         if b.pending == 0:
+            self._fill(b)
             self._launch(b)
+
+    @staticmethod
+    def _fill(b: _Bucket):
+        """Move the finished gradients of a bucket into its flat buffer with one multi-tensor copy
+        (one launch per bucket instead of one per parameter) and drop the originals: the bucket
+        slices become the gradients in finish()."""
+        idx = [i for i, got in enumerate(b.got) if got and b.params[i].grad is not None
+               and b.params[i].grad.data_ptr() != b.views[i].data_ptr()]
+        if idx:
+            torch._foreach_copy_([b.views[i] for i in idx], [b.params[i].grad for i in idx])
+        for i in idx:
+            b.params[i].grad = None
 
     def _launch(self, b: _Bucket):
         if self.overlap:
@@ -103,6 +114,7 @@ class GradSync:
             if b.pending != 0:
                 # some parameter received no gradient this step: its slice counts as zero, and the
                 # bucket is reduced anyway (every rank must join every collective)
+                self._fill(b)
                 for i, got in enumerate(b.got):
                     if not got:
                         b.views[i].zero_()
