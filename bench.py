@@ -83,6 +83,7 @@ class KernelTimer:
         self.ops = ops
         self.records = []          # (key, start_event, end_event, work, unit)
         self.saved = {}
+        self.shapes = []           # DVAE_BENCH_DEBUG: tensor-argument shapes of every timed launch
 
     def _wrap(self, name, keyfn):
         orig = getattr(self.ops, name)
@@ -95,6 +96,8 @@ class KernelTimer:
             r = orig(*a, **k)
             e.record()
             self.records.append((key, s, e, work, unit))
+            if os.environ.get('DVAE_BENCH_DEBUG'):
+                self.shapes.append([tuple(t.shape) for t in a if torch.is_tensor(t)])
             return r
         setattr(self.ops, name, wrapped)
 
@@ -113,11 +116,12 @@ class KernelTimer:
         def conv_bn_key(x, wp, bn_y, aff):
             key, work, unit = conv_key(x, None, None, 0, wp, True)
             if unit == 'byte':
-                work += float(bn_y.numel() * 4)
-            return key, work, unit
+                return key + ',bnstat', work + float(bn_y.numel() * 4), unit
+            return key[:-1] + ',bnstat>', work, unit
 
         def deconv_bn_key(x, wp, bn_y, aff):
-            return deconv_key(x, None, None, 0, wp, True)
+            key, work, unit = deconv_key(x, None, None, 0, wp, True)
+            return key[:-1] + ',bnstat>', work, unit
 
         def deconv_key(x, sc, sh, act, wp, stats):
             N, H, W, Cin = x.shape
@@ -199,24 +203,36 @@ class KernelTimer:
             setattr(self.ops, n, f)
 
     def summary(self, steps):
+        """One row per kernel group.  Every step issues the same launches in the same order, so the
+        records split into `steps` equal runs; a group's time per step is the MEDIAN over the steps of
+        its per-step sum (one stalled launch, e.g. behind an allocation, does not move it)."""
         torch.cuda.synchronize()
+        per = len(self.records) // steps
+        if per * steps != len(self.records):
+            raise RuntimeError(f"{len(self.records)} timed launches do not split into {steps} equal steps")
         agg = {}
-        for key, s, e, work, unit in self.records:
-            a = agg.setdefault(key, {'ms': 0.0, 'launches': 0, 'work': 0.0, 'unit': unit})
-            a['ms'] += s.elapsed_time(e)
+        for i, (key, s, e, work, unit) in enumerate(self.records):
+            a = agg.setdefault(key, {'ms': [0.0] * steps, 'launches': 0, 'work': 0.0, 'unit': unit})
+            ms = s.elapsed_time(e)
+            a['ms'][i // per] += ms
             a['launches'] += 1
             a['work'] += work
+            if os.environ.get('DVAE_BENCH_DEBUG'):
+                rate = work / ms / (1e9 if unit == 'flop' else 1e6)
+                print('launch', i // per, key, round(ms * 1e3, 1), 'us', round(rate, 1),
+                      'TFLOP/s' if unit == 'flop' else 'GB/s', self.shapes[i], file=sys.stderr)
         rows = []
         for key, a in agg.items():
-            sec = a['ms'] / 1e3
+            ms = sorted(a['ms'])[steps // 2]
+            sec, work, launches = ms / 1e3, a['work'] / steps, a['launches'] // steps
             if a['unit'] == 'flop':
-                ach, peak, u, bound = a['work'] / sec / 1e12, PEAK_FP32_MFMA_TFLOPS, 'TFLOP/s', 'mfma'
+                ach, peak, u, bound = work / sec / 1e12, PEAK_FP32_MFMA_TFLOPS, 'TFLOP/s', 'mfma'
             else:
-                ach, peak, u, bound = a['work'] / sec / 1e9, PEAK_HBM_GBS, 'GB/s', 'hbm'
+                ach, peak, u, bound = work / sec / 1e9, PEAK_HBM_GBS, 'GB/s', 'hbm'
             rows.append({'kernel': key, 'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': u,
-                         'frac': round(ach / peak, 4), 'ms_per_step': round(a['ms'] / steps, 4),
-                         'launches_per_step': a['launches'] // steps,
-                         'avg_launch_us': round(a['ms'] * 1e3 / a['launches'], 2)})
+                         'frac': round(ach / peak, 4), 'ms_per_step': round(ms, 4),
+                         'launches_per_step': launches,
+                         'avg_launch_us': round(ms * 1e3 / launches, 2)})
         rows.sort(key=lambda r: -r['ms_per_step'])
         return rows
 
@@ -405,9 +421,10 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_kernel_table and args.precision == 'fp32':
         step = train_step if args.mode == 'train' else infer_step      # kernels are timed on eager launches
+        step(0)                      # untimed: the eager path's buffers come out of the allocator's cache afterwards
         kt = KernelTimer(ops)
         kt.install()
-        nprof = 3
+        nprof = 5
         for i in range(nprof):
             step(i)
         rows = kt.summary(nprof)

@@ -16,10 +16,14 @@ from collections import defaultdict
 
 def bench_label(name):
     """the label bench.py's kernel table uses for a kernel symbol (None when it has no single one)"""
-    m = re.match(r'void conv_fwd_kernel<Tile<\d+, (\d+), .*?>, (\d), (true|false), (true|false)>', name)
-    if m:
+    m = re.match(r'void conv_fwd_kernel<Tile<\d+, (\d+), .*?>, (\d), (true|false), (true|false), (true|false)>',
+                 name)
+    if m:       # <tile, mode, single input channel, bf16 operands, fused BatchNorm-backward statistics>
         return f"conv_fwd_kernel<T{m.group(1)},{'deconv' if m.group(2) == '1' else 'conv'}" \
-               f"{',c1' if m.group(3) == 'true' else ''}>"
+               f"{',c1' if m.group(3) == 'true' else ''}{',bnstat' if m.group(5) == 'true' else ''}>"
+    m = re.match(r'void conv_c1_kernel<\d+, (true|false)>', name)
+    if m:
+        return 'conv_c1_kernel' + (',bnstat' if m.group(1) == 'true' else '')
     m = re.match(r'void conv_wgrad_kernel<Tile<(\d+), (\d+), .*?>, (true|false)>', name)
     if m:
         return f'conv_wgrad_kernel<T{m.group(1)}x{m.group(2)}>'
