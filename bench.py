@@ -177,10 +177,9 @@ class KernelTimer:
             K = H + (0 if x is None else x.shape[1])
             return "lstm_step_fwd_kernel", 2.0 * B * 4 * H * K, 'flop'
 
-        def skinny_key(dg, w, w2, out, acc):
-            B, K = dg.shape
-            N = w.shape[1]
-            return "skinny_gemm_nn_kernel", 2.0 * B * N * K * (2 if w2 is not None else 1), 'flop'
+        def skinny_key(a, wt, out, acc):
+            B, K = a.shape
+            return "skinny_gemm_nt_kernel", 2.0 * B * wt.shape[0] * K, 'flop'
 
         self._wrap('conv4s2_fwd', conv_key)
         self._wrap('deconv4s2_fwd', deconv_key)
@@ -196,7 +195,7 @@ class KernelTimer:
         self._wrap('recon_loss_fwd', loss_fwd_key)
         self._wrap('recon_loss_bwd', loss_bwd_key)
         self._wrap('lstm_step_fwd', lstm_key)
-        self._wrap('skinny_gemm_nn', skinny_key)
+        self._wrap('skinny_gemm_nt', skinny_key)
 
     def remove(self):
         for n, f in self.saved.items():

@@ -1,101 +1,40 @@
 // LSTM recurrence kernels.  The recurrence is latency bound (B rows x 4H gate columns x H deep per
-// step, strictly sequential in time), so the work of one step is spread over as many SIMDs as the
-// problem allows: a workgroup owns a 32-row x 32-column output tile (for the forward step: 4 gates x 8
-// hidden units, so the cell update is local to the workgroup) and its four waves split K between
-// them, each feeding v_mfma_f32_32x32x2_f32 from its own quarter of every 128-deep K chunk; the four
-// partial tiles are summed through LDS, then the sigmoid/tanh cell update is applied in the same
-// kernel.  Steps are separate launches on one stream (captured into a graph by the caller): on this
-// chip a kernel boundary is cheaper than a grid-wide barrier inside a persistent launch.
+// step, strictly sequential in time), so one step is shaped for the shortest path through a single
+// launch, not for operand reuse: the output is cut into as many small tiles as there are compute units
+// (forward: 32 rows x [4 gates x 8 hidden units], so the cell update is local to the workgroup;
+// backward: 16 x 16), the waves of a workgroup split K between them, and every wave loads its operand
+// fragments straight from memory (L2 resident: weights and one step's state) into the register layout
+// of v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 -- all loads of a wave are in flight at once, no
+// staging through LDS, one barrier.  The partial tiles are summed through LDS and the sigmoid/tanh
+// cell update (forward) or the accumulation into dh (backward) happens in the same kernel.  Steps are
+// separate launches on one stream (captured into a graph by the caller): on this chip a kernel
+// boundary is cheaper than a grid-wide barrier inside a persistent launch.
 #include "common.h"
 #include "../../include/dvae_hip.h"
 
 #define ST(s) ((hipStream_t)(s))
-#define KS_CH 128           // K chunk staged per iteration
-#define KS_LDA (KS_CH + 4)  // k-contiguous image: [32 rows][KS_CH + 4]
-#define KS_LDB_RC 36        // row-contiguous image: [KS_CH k][32 + 4]
 #define KS_RED_LD 40
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-// ---- staging helpers (256 threads move a 32 x 128 operand chunk = 4 float4 each) ---------------
-// k-contiguous source: row pointer + k
-__device__ __forceinline__ void ks_fetch_kc(const float* __restrict__ base, int64_t ld, int64_t row0, int64_t rows,
-                                            int64_t k0, int64_t K, float4 (&r)[4]) {
+// NF consecutive 16-byte pieces of one k-contiguous operand row, `stride` floats apart, starting at
+// k0: piece q covers k0 + stride*q .. +3.  Branch-free (clamped address, value zeroed afterwards) so
+// that the compiler keeps all the loads of a wave in flight together.  K%4 == 0.
+template <int NF>
+__device__ __forceinline__ void frag_load(const float* __restrict__ rowp, bool rowok, int64_t k0, int stride,
+                                          int64_t K, f32x4 (&r)[NF]) {
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int L = v * 256 + threadIdx.x;
-    const int row = L >> 5, ch = L & 31;
-    const int64_t gr = row0 + row, k = k0 + 4 * ch;
-    r[v] = (base != nullptr && gr < rows && k < K) ? *reinterpret_cast<const float4*>(base + gr * ld + k)
-                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-}
-__device__ __forceinline__ void ks_store_kc(float* lds, const float4 (&r)[4]) {
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int L = v * 256 + threadIdx.x;
-    *reinterpret_cast<float4*>(lds + (L >> 5) * KS_LDA + 4 * (L & 31)) = r[v];
-  }
-}
-// gate-row gather for the forward step: tile row c (0..31) is weight row (c>>3)*H + j0 + (c&7)
-__device__ __forceinline__ void ks_fetch_gate_rows(const float* __restrict__ w, int64_t ld, int64_t H, int64_t j0,
-                                                   int64_t k0, int64_t K, float4 (&r)[4]) {
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int L = v * 256 + threadIdx.x;
-    const int c = L >> 5, ch = L & 31;
-    const int64_t wr = (int64_t)(c >> 3) * H + j0 + (c & 7), k = k0 + 4 * ch;
-    r[v] = (w != nullptr && k < K) ? *reinterpret_cast<const float4*>(w + wr * ld + k)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-}
-// row-contiguous source [K][N]: chunk rows k0..k0+127, columns n0..n0+31
-__device__ __forceinline__ void ks_fetch_rc(const float* __restrict__ base, int64_t ld, int64_t n0, int64_t N,
-                                            int64_t k0, int64_t K, float4 (&r)[4]) {
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int L = v * 256 + threadIdx.x;
-    const int kr = L >> 3, c4 = L & 7;
-    const int64_t k = k0 + kr, n = n0 + 4 * c4;
-    r[v] = (k < K && n < N) ? *reinterpret_cast<const float4*>(base + k * ld + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-}
-__device__ __forceinline__ void ks_store_rc(float* lds, const float4 (&r)[4]) {
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int L = v * 256 + threadIdx.x;
-    *reinterpret_cast<float4*>(lds + (L >> 3) * KS_LDB_RC + 4 * (L & 7)) = r[v];
+  for (int q = 0; q < NF; ++q) {
+    const int64_t kk = k0 + stride * q;
+    const bool ok = rowok && kk < K;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + (ok ? kk : 0));
+    r[q] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 }
 
-template <bool BKC>
-__device__ __forceinline__ void ks_mma(const float* __restrict__ As, const float* __restrict__ Bs, f32x16& acc,
-                                       int wave, int lane) {
-  const int l31 = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int kk = 32 * wave + 8 * q + 4 * h;
-    const float4 av = *reinterpret_cast<const float4*>(As + l31 * KS_LDA + kk);
-    float b0, b1, b2, b3;
-    if (BKC) {
-      const float4 bv = *reinterpret_cast<const float4*>(Bs + l31 * KS_LDA + kk);
-      b0 = bv.x; b1 = bv.y; b2 = bv.z; b3 = bv.w;
-    } else {
-      b0 = Bs[(kk + 0) * KS_LDB_RC + l31];
-      b1 = Bs[(kk + 1) * KS_LDB_RC + l31];
-      b2 = Bs[(kk + 2) * KS_LDB_RC + l31];
-      b3 = Bs[(kk + 3) * KS_LDB_RC + l31];
-    }
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc, 0, 0, 0);
-  }
-}
-
-// write the wave's partial tile to red[wave][32][KS_RED_LD]
+// write the wave's partial 32x32 tile to red[wave][32][KS_RED_LD]
 __device__ __forceinline__ void ks_spill(float* red, const f32x16& acc, int wave, int lane) {
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -104,9 +43,6 @@ __device__ __forceinline__ void ks_spill(float* red, const f32x16& acc, int wave
     red[(wave * 32 + row) * KS_RED_LD + l31] = acc[r];
   }
 }
-
-#define KS_STAGE_KC (32 * KS_LDA)
-#define KS_STAGE_RC (KS_CH * KS_LDB_RC)
 
 // ------------------------------------------------------------------------------------------------
 // forward step
@@ -126,68 +62,75 @@ struct LstmFwdArgs {
   int64_t B, H;
 };
 
-__global__ void __launch_bounds__(256) lstm_step_fwd_kernel(LstmFwdArgs g) {
-  __shared__ __attribute__((aligned(16))) float smem[4 * KS_STAGE_KC];  // 2 stages x (A, B)
+#define FWD_WAVES 4     // the cell update below maps 256 threads onto 32 rows x 8 hidden units
+__global__ void __launch_bounds__(64 * FWD_WAVES) lstm_step_fwd_kernel(LstmFwdArgs g) {
+  __shared__ float red[FWD_WAVES * 32 * KS_RED_LD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
   const int64_t j0 = (int64_t)blockIdx.x * 8, b0 = (int64_t)blockIdx.y * 32;
-  const int nx = (g.x != nullptr) ? (int)((g.I + KS_CH - 1) / KS_CH) : 0;
-  const int nh = (g.h_prev != nullptr) ? (int)((g.H + KS_CH - 1) / KS_CH) : 0;
-  const int nchunks = nx + nh;
+  // lane l31 feeds batch row b0 + l31 as the A operand and gate row (l31>>3)*H + j0 + (l31&7) as B
+  const int64_t row = b0 + l31;
+  const bool rowok = row < g.B;
+  const int64_t rc = rowok ? row : g.B - 1;
+  const int64_t wr = (int64_t)(l31 >> 3) * g.H + j0 + (l31 & 7);
+
+  // operands of the cell update (thread -> row bl, hidden unit jj): requested first, so that they
+  // arrive while the products are formed
+  const int bl = threadIdx.x >> 3, jj = threadIdx.x & 7;
+  const int64_t b = b0 + bl, j = j0 + jj;
+  // Unconditional loads (absent operands read a dummy address and are dropped at the point of
+  // use), so that nothing here makes the wave wait before the operand loads below are issued.
+  const int64_t bb = b < g.B ? b : g.B - 1;
+  const float* xpp = g.xproj ? g.xproj + bb * g.ld_xproj + j : g.w_hh;
+  const float* bip = g.b_ih ? g.b_ih + j : g.w_hh;
+  const float* bhp = g.b_ih ? g.b_hh + j : g.w_hh;
+  const int64_t xstep = g.xproj ? g.H : 0, bstep = g.b_ih ? g.H : 0;
+  float raw_x[4], raw_bi[4], raw_bh[4];
+#pragma unroll
+  for (int gt = 0; gt < 4; ++gt) {
+    raw_x[gt] = xpp[gt * xstep];
+    raw_bi[gt] = bip[gt * bstep];
+    raw_bh[gt] = bhp[gt * bstep];
+  }
+  const float raw_c = *(g.c_prev ? g.c_prev + bb * g.ld_c + j : g.w_hh);
 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-  float4 ra[4], rb[4];
-  auto fetch = [&](int c) {
-    if (c < nx) {
-      ks_fetch_kc(g.x, g.ld_x, b0, g.B, (int64_t)c * KS_CH, g.I, ra);
-      ks_fetch_gate_rows(g.w_ih, g.I, g.H, j0, (int64_t)c * KS_CH, g.I, rb);
-    } else {
-      ks_fetch_kc(g.h_prev, g.ld_h, b0, g.B, (int64_t)(c - nx) * KS_CH, g.H, ra);
-      ks_fetch_gate_rows(g.w_hh, g.H, g.H, j0, (int64_t)(c - nx) * KS_CH, g.H, rb);
+#pragma unroll
+  for (int seg = 0; seg < 2; ++seg) {
+    const float* A = seg == 0 ? g.x : g.h_prev;
+    if (A == nullptr) continue;
+    const int64_t K = seg == 0 ? g.I : g.H;
+    const float* ap = A + rc * (seg == 0 ? g.ld_x : g.ld_h);
+    const float* bp = (seg == 0 ? g.w_ih : g.w_hh) + wr * K;
+    // a wave takes 64 consecutive k per pass: eight MFMA quads, each fed by one 16-byte load per operand
+    for (int64_t k0 = (int64_t)wave * 64; k0 < K; k0 += 64 * FWD_WAVES) {
+      f32x4 av[8], bv[8];
+      frag_load<8>(ap, rowok, k0 + 4 * h, 8, K, av);
+      frag_load<8>(bp, true, k0 + 4 * h, 8, K, bv);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][0], bv[q][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][1], bv[q][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][2], bv[q][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][3], bv[q][3], acc, 0, 0, 0);
+      }
     }
-  };
-  if (nchunks > 0) {
-    fetch(0);
-    ks_store_kc(smem, ra);
-    ks_store_kc(smem + KS_STAGE_KC, rb);
   }
-  __syncthreads();
-  int cur = 0;
-  for (int c = 0; c < nchunks; ++c) {
-    const bool more = c + 1 < nchunks;
-    if (more) fetch(c + 1);
-    const float* st = smem + cur * 2 * KS_STAGE_KC;
-    ks_mma<true>(st, st + KS_STAGE_KC, acc, wave, lane);
-    if (more) {
-      float* nxp = smem + (cur ^ 1) * 2 * KS_STAGE_KC;
-      ks_store_kc(nxp, ra);
-      ks_store_kc(nxp + KS_STAGE_KC, rb);
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
-  float* red = smem;
   ks_spill(red, acc, wave, lane);
   __syncthreads();
-  // cell update: thread -> (row b, hidden unit jj)
-  const int bl = threadIdx.x >> 3, jj = threadIdx.x & 7;
-  const int64_t b = b0 + bl, j = j0 + jj;
   if (b < g.B) {
     float pre[4];
 #pragma unroll
     for (int gt = 0; gt < 4; ++gt) {
       const int col = gt * 8 + jj;
-      float s = red[(0 * 32 + bl) * KS_RED_LD + col] + red[(1 * 32 + bl) * KS_RED_LD + col] +
-                red[(2 * 32 + bl) * KS_RED_LD + col] + red[(3 * 32 + bl) * KS_RED_LD + col];
-      const int64_t gc = (int64_t)gt * g.H + j;
-      if (g.xproj) s += g.xproj[b * g.ld_xproj + gc];
-      if (g.b_ih) s += g.b_ih[gc] + g.b_hh[gc];
-      pre[gt] = s;
+      const float s = red[(0 * 32 + bl) * KS_RED_LD + col] + red[(1 * 32 + bl) * KS_RED_LD + col] +
+                      red[(2 * 32 + bl) * KS_RED_LD + col] + red[(3 * 32 + bl) * KS_RED_LD + col];
+      pre[gt] = (s + (g.xproj ? raw_x[gt] : 0.f)) + (g.b_ih ? raw_bi[gt] + raw_bh[gt] : 0.f);
     }
+    const float cp = g.c_prev ? raw_c : 0.f;
     const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
-    const float cp = g.c_prev ? g.c_prev[b * g.ld_c + j] : 0.f;
     const float cn = fg * cp + ig * gg;
     const float hn = og * tanhf(cn);
     float* go = g.gates_out + b * 4 * g.H;
@@ -216,7 +159,7 @@ extern "C" int dvae_lstm_step_fwd_f32(const float* xproj, int64_t ld_xproj, cons
   LstmFwdArgs g{xproj, ld_xproj, x, ld_x, w_ih, I, h_prev, ld_h, c_prev, ld_c, w_hh, b_ih, b_hh,
                 gates_out, h_out, ld_hout, c_out, ld_cout, B, H};
   const dim3 grid((unsigned)(H / 8), (unsigned)ceil_div64(B, 32));
-  hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(256), 0, ST(stream), g);
+  hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(64 * FWD_WAVES), 0, ST(stream), g);
   DVAE_LAUNCH_CHECK("lstm_step_fwd");
   return 0;
 }
@@ -260,74 +203,70 @@ extern "C" int dvae_lstm_step_bwd_pointwise_f32(const float* dh, int64_t ld_dh, 
 
 struct SkinnyArgs {
   const float* a; int64_t ld_a;
-  const float* w;
-  const float* w2;
+  const float* wt; int64_t ld_wt;
   float* out; int64_t ld_out;
   int64_t B, N, K;
   int accumulate;
 };
 
-__global__ void __launch_bounds__(256) skinny_gemm_nn_kernel(SkinnyArgs g) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * (KS_STAGE_KC + KS_STAGE_RC)];
+#define SK_WAVES 8     // waves of a workgroup, K split between them
+#define SK_NF 8        // 16-byte pieces per operand and pass: a wave covers 16*SK_NF consecutive k per pass
+#define SK_RED_LD 17
+
+// out[16 x 16 tile] (+)= a[16 rows][K] * wt[16 rows][K]^T.  Lane (i = lane&15, q = lane>>4) holds, per
+// 16-deep group, a[row i][k..k+3] and wt[col i][k..k+3] with k = group + 4q: component m of the two
+// 16-byte pieces is the operand pair of one v_mfma_f32_16x16x4_f32 (its four k are group + 4q + m).
+__global__ void __launch_bounds__(64 * SK_WAVES) skinny_gemm_nt_kernel(SkinnyArgs g) {
+  __shared__ float red[SK_WAVES * 16 * SK_RED_LD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t n0 = (int64_t)blockIdx.x * 32, b0 = (int64_t)blockIdx.y * 32;
-  const int per = (int)((g.K + KS_CH - 1) / KS_CH);
-  const int nchunks = per * (g.w2 ? 2 : 1);
-  f32x16 acc;
+  const int i = lane & 15, q = lane >> 4;
+  const int64_t n0 = (int64_t)blockIdx.x * 16, b0 = (int64_t)blockIdx.y * 16;
+  const bool rowok = b0 + i < g.B, colok = n0 + i < g.N;
+  const float* ap = g.a + (rowok ? b0 + i : g.B - 1) * g.ld_a;
+  const float* bp = g.wt + (colok ? n0 + i : g.N - 1) * g.ld_wt;
+  // the value to accumulate onto is requested first (threads 0..255 own one output each)
+  const int orow = (threadIdx.x >> 4) & 15, ocol = threadIdx.x & 15;
+  const bool owner = threadIdx.x < 256 && b0 + orow < g.B && n0 + ocol < g.N;
+  float* const op = g.out + (b0 + orow) * g.ld_out + n0 + ocol;
+  float prev = 0.f;
+  if (owner && g.accumulate) prev = *op;
+  // two accumulators: consecutive MFMAs of a wave do not wait for each other's result
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int64_t k0 = (int64_t)wave * 16 * SK_NF; k0 < g.K; k0 += 16 * SK_NF * SK_WAVES) {
+    f32x4 av[SK_NF], bv[SK_NF];
+    frag_load<SK_NF>(ap, rowok, k0 + 4 * q, 16, g.K, av);
+    frag_load<SK_NF>(bp, colok, k0 + 4 * q, 16, g.K, bv);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float4 ra[4], rb[4];
-  auto fetch = [&](int c) {
-    const int seg = c / per, cc = c - seg * per;
-    ks_fetch_kc(g.a, g.ld_a, b0, g.B, (int64_t)cc * KS_CH, g.K, ra);
-    ks_fetch_rc(seg == 0 ? g.w : g.w2, g.N, n0, g.N, (int64_t)cc * KS_CH, g.K, rb);
-  };
-  fetch(0);
-  ks_store_kc(smem, ra);
-  ks_store_rc(smem + KS_STAGE_KC, rb);
-  __syncthreads();
-  int cur = 0;
-  for (int c = 0; c < nchunks; ++c) {
-    const bool more = c + 1 < nchunks;
-    if (more) fetch(c + 1);
-    const float* st = smem + cur * (KS_STAGE_KC + KS_STAGE_RC);
-    ks_mma<false>(st, st + KS_STAGE_KC, acc, wave, lane);
-    if (more) {
-      float* nxp = smem + (cur ^ 1) * (KS_STAGE_KC + KS_STAGE_RC);
-      ks_store_kc(nxp, ra);
-      ks_store_rc(nxp + KS_STAGE_KC, rb);
+    for (int f = 0; f < SK_NF; ++f) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][0], bv[f][0], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][1], bv[f][1], acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][2], bv[f][2], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][3], bv[f][3], acc2, 0, 0, 0);
     }
-    __syncthreads();
-    cur ^= 1;
   }
-  float* red = smem;
-  ks_spill(red, acc, wave, lane);
-  __syncthreads();
-  // 32 x 32 outputs, 4 per thread
+  acc += acc2;
+  // D: row = 4q + r, column = i
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int i = e * 256 + threadIdx.x;
-    const int row = i >> 5, col = i & 31;
-    const int64_t b = b0 + row, n = n0 + col;
-    if (b < g.B && n < g.N) {
-      float s = red[(0 * 32 + row) * KS_RED_LD + col] + red[(1 * 32 + row) * KS_RED_LD + col] +
-                red[(2 * 32 + row) * KS_RED_LD + col] + red[(3 * 32 + row) * KS_RED_LD + col];
-      float* p = g.out + b * g.ld_out + n;
-      if (g.accumulate) s += *p;
-      *p = s;
-    }
+  for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * q + r) * SK_RED_LD + i] = acc[r];
+  __syncthreads();
+  if (owner) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) s += red[(w * 16 + orow) * SK_RED_LD + ocol];
+    *op = s + prev;
   }
 }
 
-extern "C" int dvae_skinny_gemm_nn_f32(const float* dg, int64_t ld_dg, const float* w, const float* w2, float* out,
+extern "C" int dvae_skinny_gemm_nt_f32(const float* a, int64_t ld_a, const float* wt, int64_t ld_wt, float* out,
                                        int64_t ld_out, int64_t B, int64_t N, int64_t K, int accumulate,
                                        dvae_stream_t stream) {
-  DVAE_REQUIRE(B > 0 && N > 0 && K > 0, "skinny_gemm_nn: empty");
-  DVAE_REQUIRE(K % 4 == 0 && N % 4 == 0 && ld_dg % 4 == 0, "skinny_gemm_nn: K, N, ld_dg must be multiples of 4");
-  DVAE_REQUIRE(aligned16(dg) && aligned16(w) && (w2 == nullptr || aligned16(w2)), "skinny_gemm_nn: 16-byte alignment");
-  SkinnyArgs g{dg, ld_dg, w, w2, out, ld_out, B, N, K, accumulate};
-  const dim3 grid((unsigned)ceil_div64(N, 32), (unsigned)ceil_div64(B, 32));
-  hipLaunchKernelGGL(skinny_gemm_nn_kernel, grid, dim3(256), 0, ST(stream), g);
-  DVAE_LAUNCH_CHECK("skinny_gemm_nn");
+  DVAE_REQUIRE(B > 0 && N > 0 && K > 0, "skinny_gemm_nt: empty");
+  DVAE_REQUIRE(a && wt && out, "skinny_gemm_nt: null argument");
+  DVAE_REQUIRE(K % 4 == 0 && ld_a % 4 == 0 && ld_wt % 4 == 0, "skinny_gemm_nt: K, ld_a, ld_wt must be multiples of 4");
+  DVAE_REQUIRE(aligned16(a) && aligned16(wt), "skinny_gemm_nt: 16-byte alignment");
+  SkinnyArgs g{a, ld_a, wt, ld_wt, out, ld_out, B, N, K, accumulate};
+  const dim3 grid((unsigned)ceil_div64(N, 16), (unsigned)ceil_div64(B, 16));
+  hipLaunchKernelGGL(skinny_gemm_nt_kernel, grid, dim3(64 * SK_WAVES), 0, ST(stream), g);
+  DVAE_LAUNCH_CHECK("skinny_gemm_nt");
   return 0;
 }

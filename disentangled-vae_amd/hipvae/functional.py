@@ -384,6 +384,7 @@ class LSTMEncoder(torch.autograd.Function):
             dgs = [_empty(T, B, 4 * H, like=dfinal) for _ in range(D)]
             dcs = [[_empty(B, H, like=dfinal), _empty(B, H, like=dfinal)] for _ in range(D)]
             w_hhs = [weights[(l * D + d) * 4 + 1].contiguous() for d in range(D)]
+            w_hh_t = [w.t().contiguous() for w in w_hhs]      # [H, 4H]: k-contiguous rows for dh = dG * W_hh
             with _TwoLanes(dfinal, D == 2) as lanes:
                 for i in range(T - 1, -1, -1):                    # walk the recurrences backwards
                     for d in range(D):
@@ -396,7 +397,7 @@ class LSTMEncoder(torch.autograd.Function):
                                                         gates[d, t], None if tp is None else cseq[d, tp], cseq[d, t],
                                                         dgs[d][t], dc[i & 1])
                             if tp is not None:
-                                ops.skinny_gemm_nn(dgs[d][t], w_hhs[d], None, dh[tp][:, sl], True)
+                                ops.skinny_gemm_nt(dgs[d][t], w_hh_t[d], dh[tp][:, sl], True)
             for d in range(D):
                 k = (l * D + d) * 4
                 w_ih = weights[k].contiguous()
@@ -449,14 +450,21 @@ class LSTMDecoder(torch.autograd.Function):
         gates = _empty(L, T, B, 4 * H, like=h0)
         w = [t.detach().contiguous() for t in weights]
         x0 = init_c.expand(B, H)                      # row stride 0: every row reads the same vector
+        # a single layer is fed its own previous output: x_t == h_{t-1} for t > 0, so
+        # x W_ih^T + h W_hh^T = h (W_ih + W_hh)^T and the step is H deep instead of 2H
+        w_comb = (w[0] + w[1]) if (L == 1 and T > 1) else None
         for t in range(T):
             for l in range(L):
+                h_prev = h0[:, l * H:(l + 1) * H] if t == 0 else hs[l, t - 1]
+                c_prev = c0[:, l * H:(l + 1) * H] if t == 0 else cs[l, t - 1]
+                if w_comb is not None and t > 0:
+                    ops.lstm_step_fwd(None, None, None, h_prev, c_prev, w_comb, w[2], w[3],
+                                      gates[l, t], hs[l, t], cs[l, t])
+                    continue
                 if l == 0:
                     x = x0 if t == 0 else hs[L - 1, t - 1]
                 else:
                     x = hs[l - 1, t]
-                h_prev = h0[:, l * H:(l + 1) * H] if t == 0 else hs[l, t - 1]
-                c_prev = c0[:, l * H:(l + 1) * H] if t == 0 else cs[l, t - 1]
                 ops.lstm_step_fwd(None, x, w[4 * l], h_prev, c_prev, w[4 * l + 1], w[4 * l + 2], w[4 * l + 3],
                                   gates[l, t], hs[l, t], cs[l, t])
         states = ops.permute3(hs[L - 1], (T, B, H), (1, 0, 2))         # [B, T, H]
@@ -477,9 +485,14 @@ class LSTMDecoder(torch.autograd.Function):
         dc0 = _empty(B, L * H, like=h0)
         dcbuf = [[_empty(B, H, like=h0), _empty(B, H, like=h0)] for _ in range(L)]
         dx0 = _empty(B, H, like=h0)
+        # dh = dG * W needs W's columns as k-contiguous rows: transposed copies, once per backward;
+        # for a single layer both paths of a step t > 0 end in h_{t-1}, so they share W_ih + W_hh
+        w_ih_t = [weights[4 * l].t().contiguous() for l in range(L)]
+        w_hh_t = [weights[4 * l + 1].t().contiguous() for l in range(L)]
+        w_comb_t = (w_ih_t[0] + w_hh_t[0]) if (L == 1 and T > 1) else None
         for t in range(T - 1, -1, -1):
             for l in range(L - 1, -1, -1):
-                w_ih, w_hh = weights[4 * l], weights[4 * l + 1]
+                w_ih, w_hh = w_ih_t[l], w_hh_t[l]
                 c_prev = c0[:, l * H:(l + 1) * H] if t == 0 else cs[l, t - 1]
                 dc_in = None if t == T - 1 else dcbuf[l][(t + 1) & 1]
                 dc_out = dc0[:, l * H:(l + 1) * H] if t == 0 else dcbuf[l][t & 1]
@@ -489,17 +502,17 @@ class LSTMDecoder(torch.autograd.Function):
                 rec_acc = t > 0
                 # input path -> layer below at the same step, or the top layer's previous output
                 if l > 0:
-                    ops.skinny_gemm_nn(dg[l, t], w_hh, None, rec_target, rec_acc)
-                    ops.skinny_gemm_nn(dg[l, t], w_ih, None, dhs[l - 1, t], True)
+                    ops.skinny_gemm_nt(dg[l, t], w_hh, rec_target, rec_acc)
+                    ops.skinny_gemm_nt(dg[l, t], w_ih, dhs[l - 1, t], True)
                 elif t > 0:
                     if L == 1:
-                        ops.skinny_gemm_nn(dg[0, t], w_hh, w_ih, rec_target, True)
+                        ops.skinny_gemm_nt(dg[0, t], w_comb_t, rec_target, True)
                     else:
-                        ops.skinny_gemm_nn(dg[0, t], w_hh, None, rec_target, True)
-                        ops.skinny_gemm_nn(dg[0, t], w_ih, None, dhs[L - 1, t - 1], True)
+                        ops.skinny_gemm_nt(dg[0, t], w_hh, rec_target, True)
+                        ops.skinny_gemm_nt(dg[0, t], w_ih, dhs[L - 1, t - 1], True)
                 else:
-                    ops.skinny_gemm_nn(dg[0, 0], w_hh, None, rec_target, False)
-                    ops.skinny_gemm_nn(dg[0, 0], w_ih, None, dx0, False)
+                    ops.skinny_gemm_nt(dg[0, 0], w_hh, rec_target, False)
+                    ops.skinny_gemm_nt(dg[0, 0], w_ih, dx0, False)
         dinit = ops.bias_act_bwd(dx0, None, ops.ACT_NONE, True).view(1, H)
         grads = [None] * (4 * L)
         for l in range(L):

@@ -443,14 +443,15 @@ def lstm_step_bwd_pointwise(dh, dc, gates, c_prev, c, dgates, dc_prev):
           'lstm_step_bwd_pointwise')
 
 
-def skinny_gemm_nn(dg: Tensor, w: Tensor, w2: Optional[Tensor], out: Tensor, accumulate: bool):
-    """out[B,N] (+)= dg[B,K] @ w[K,N] (+ dg @ w2)."""
-    _chk2(dg, w, w2, out)
-    B, K = dg.shape
-    N = w.shape[1]
-    assert w.shape[0] == K and w.is_contiguous() and (w2 is None or (w2.shape == w.shape and w2.is_contiguous()))
-    check(lib.dvae_skinny_gemm_nn_f32(_p(dg), dg.stride(0), _p(w), _p(w2), _p(out), out.stride(0), B, N, K,
-                                      int(accumulate), _stream()), 'skinny_gemm_nn')
+def skinny_gemm_nt(a: Tensor, wt: Tensor, out: Tensor, accumulate: bool):
+    """out[B,N] (+)= a[B,K] @ wt[N,K]^T; rows of a, wt and out may be strided (unit stride inside a row)."""
+    _chk2(a, wt, out)
+    B, K = a.shape
+    N = wt.shape[0]
+    assert wt.shape[1] == K and out.shape == (B, N)
+    assert a.stride(1) == 1 and wt.stride(1) == 1 and out.stride(1) == 1
+    check(lib.dvae_skinny_gemm_nt_f32(_p(a), a.stride(0), _p(wt), wt.stride(0), _p(out), out.stride(0), B, N, K,
+                                      int(accumulate), _stream()), 'skinny_gemm_nt')
 
 
 # ---------------------------------------------------------------------------- optimiser

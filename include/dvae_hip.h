@@ -233,9 +233,11 @@ int dvae_lstm_step_bwd_pointwise_f32(const float* dh, int64_t ld_dh, const float
                                      const float* gates, const float* c_prev, int64_t ld_cprev,
                                      const float* c, int64_t ld_c, float* dgates, float* dc_prev,
                                      int64_t ld_dcprev, int64_t B, int64_t H, dvae_stream_t stream);
-/* Skinny GEMM of the recurrence: out[B,N] (+)= dg[B,K] * w[K,N] (+ dg * w2[K,N]); latency-oriented
- * (32x32 output tiles, K split over the four waves of a workgroup).  K%4==0, N%4==0. */
-int dvae_skinny_gemm_nn_f32(const float* dg, int64_t ld_dg, const float* w, const float* w2, float* out,
+/* Skinny GEMM of the recurrence's backward step, dh_{t-1} (+)= dG_t * W with W handed over transposed:
+ * out[B,N] (+)= a[B,K] * wt[N,K]^T, every row with its own stride (floats).  Latency-oriented: 16x16
+ * output tiles, K split over the waves of a workgroup, operands loaded straight into MFMA registers.
+ * K%4==0, ld_a%4==0, ld_wt%4==0, a and wt 16-byte aligned. */
+int dvae_skinny_gemm_nt_f32(const float* a, int64_t ld_a, const float* wt, int64_t ld_wt, float* out,
                             int64_t ld_out, int64_t B, int64_t N, int64_t K, int accumulate,
                             dvae_stream_t stream);
 

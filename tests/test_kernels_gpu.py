@@ -409,18 +409,23 @@ def test_lstm_step_bwd(ops):
     ops.lstm_step_bwd_pointwise(dev(dh2), dev(dc2), dev(gates), dev(c.detach()), dev(c2.detach()), dgates, dcp)
     assert rel_err(dgates, dp) < 5e-6 and rel_err(dcp, dc) < 5e-6
     out = torch.empty(B, H, device='cuda')
-    ops.skinny_gemm_nn(dgates, dev(w_hh), None, out, False)
+    ops.skinny_gemm_nt(dgates, dev(w_hh.t()), out, False)
     assert rel_err(out, dh) < 5e-6
-    ops.skinny_gemm_nn(dgates, dev(w_hh), dev(w_ih), out, True)
+    ops.skinny_gemm_nt(dgates, dev((w_hh + w_ih).t()), out, True)
     assert rel_err(out, dh + dp @ w_hh + dp @ w_ih) < 5e-6
 
 
-@pytest.mark.parametrize('B,N,K', [(32, 256, 1024), (70, 36, 132), (1, 4, 4)])
+@pytest.mark.parametrize('B,N,K', [(32, 256, 1024), (256, 256, 1024), (70, 36, 132), (1, 4, 4), (17, 3, 2052)])
 def test_skinny_gemm(ops, B, N, K):
     a, w = rnd(B, K, seed=74), rnd(K, N, seed=75)
-    out = torch.empty(B, N, device='cuda')
-    ops.skinny_gemm_nn(dev(a), dev(w), None, out, False)
-    assert rel_err(out, a @ w) < 2e-6
+    base = rnd(B, N, seed=76)
+    # strided rows on all three operands: column slices of wider buffers
+    abuf, wbuf, obuf = dev(torch.cat([a, a], 1)), dev(torch.cat([w.t(), w.t()], 1)), dev(torch.cat([base, base], 1))
+    ops.skinny_gemm_nt(abuf[:, K:], wbuf[:, :K], obuf[:, N:], False)
+    assert rel_err(obuf[:, N:], a @ w) < 2e-6
+    assert torch.equal(obuf[:, :N].cpu().double(), base.float().double())
+    ops.skinny_gemm_nt(abuf[:, :K], wbuf[:, K:], obuf[:, :N], True)
+    assert rel_err(obuf[:, :N], base + a @ w) < 2e-6
 
 
 # ------------------------------------------------------------------ optimiser
