@@ -127,8 +127,8 @@ class KernelTimer:
             N, H, W, Cin = x.shape
             Cout = wp.shape[1]
             fl = 2.0 * N * 4 * H * W * Cout * 4 * Cin
-            if (Cin, Cout) in ((32, 16), (64, 32)):      # few channels: the register-resident-filter kernel
-                return f"deconv_stream_kernel<{Cin},{Cout}>", fl, 'flop'
+            if (Cin, Cout) in ((32, 16), (64, 32)) and 16 <= W <= 32:   # few channels: rows through an LDS ring
+                return f"deconv_rows_kernel<{Cin},{Cout}>", fl, 'flop'
             return f"conv_fwd_kernel<{tile(Cout)},deconv>", fl, 'flop'
 
         def wgrad_key(P, ps, ph, pa, Q, qs, qh, qa):

@@ -499,25 +499,30 @@ __global__ void __launch_bounds__(256) conv_c1_kernel(ConvArgs g) {
   }
 }
 
-// Transposed convolution with few channels (Cin*Cout <= 2048): too little work per pixel for a tiled
-// GEMM whose K loop is four taps deep.  No LDS staging and no barriers: every wave owns one of the four
-// sub-pixel phases and keeps that phase's whole filter [Cout][4 taps][Cin] in registers as the A
-// operands of v_mfma_f32_16x16x4_f32; it then streams groups of sixteen consecutive input positions,
-// loading their four tap pixels straight from memory as B operands (lane = position x channel quad,
-// 16-byte loads, BatchNorm + LeakyReLU of the producing layer applied in registers) and gets four
-// consecutive output channels of one output pixel per lane: 16-byte stores that tile the pixel's
-// channel vector.  The loads of the next group are issued before the products of the current one, so
-// a wave keeps the matrix pipe busy on its own (WAVES_PER_EU waves per SIMD is all the registers
-// allow for the larger filter).  The four waves of a workgroup walk the same positions, so the taps
-// they share come out of L1.  Statistics (forward sums, or the BatchNorm-backward sums of
-// ConvArgs::bn_y) stay in registers and leave as one partial row per wave.
-// XF: the input has a load-time transform (absent scale/shift and absent activation are then the
-// identities scale 1, shift 0, slope 1, so the loop body has no branches).
+// Transposed convolution with few channels (Cin*Cout <= 2048) on frames at least sixteen pixels wide:
+// too little work per pixel for a tiled GEMM whose K loop is four taps deep.  A workgroup is four waves
+// = the four sub-pixel phases; each wave keeps its phase's whole filter [Cout][4 taps][Cin] in
+// registers as the A operands of v_mfma_f32_16x16x4_f32 and owns, with its workgroup, a contiguous run
+// of input rows.  Every input row is fetched from memory once, with full-line coalesced loads, gets
+// the producing layer's BatchNorm + LeakyReLU once, and is written into a ring of four row slots in
+// LDS whose end pixels are zero: the rows an output row pair needs are then read by all four waves as
+// MFMA B operands (lane = pixel x channel quad, 16-byte LDS reads), column taps are address offsets,
+// the frame's left/right edges need no masks, and taps above/below the frame are skipped per wave.
+// A lane ends up with four consecutive output channels of one output pixel: 16-byte stores that tile
+// the pixel's channel vector.  The row after next is in flight while the current one is multiplied;
+// one barrier per row.  Statistics (forward sums, or the BatchNorm-backward sums of ConvArgs::bn_y)
+// stay in registers and leave as one partial row per wave.
+#define ROWS_WMAX 32
 template <int CIN, int COUT, int WAVES_PER_EU, bool XF, bool BNS>
-__global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_stream_kernel(ConvArgs g) {
+__global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs g) {
   constexpr int NU = CIN / 16, NCB = COUT / 16;
+  constexpr int PS = CIN + 4;                       // pixel stride in LDS: 16-byte reads without bank conflicts
+  constexpr int C4 = CIN / 4;                       // 16-byte pieces per pixel
+  constexpr int NLD = (ROWS_WMAX * C4 + 255) / 256; // 16-byte pieces of a row per thread, at most
+  __shared__ __attribute__((aligned(16))) float ring[4][(ROWS_WMAX + 2) * PS];
   const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6, ph = phase >> 1, pw = phase & 1;
   const int i16 = lane & 15, kq = lane >> 4;
+  const int W = g.W, H = g.H;
   // component m of wa[cb][t][u] multiplies channel 16u + 4kq + m of tap t into output channel 16cb + i16
   f32x4 wa[NCB][4][NU];
 #pragma unroll
@@ -527,16 +532,16 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_stream_kernel(ConvAr
 #pragma unroll
       for (int u = 0; u < NU; ++u)
         wa[cb][t][u] = ldg4(g.wp + (((int64_t)phase * COUT + 16 * cb + i16) * 4 + t) * CIN + 16 * u + 4 * kq);
-  f32x4 sc[NU], sh[NU];
+  // loader role: this thread's pieces of a row are pieces threadIdx.x + 256 j; their channel offset is
+  // the same for every j (C4 divides 256)
+  const int lc4 = threadIdx.x % C4;
+  f32x4 sc = (f32x4){1.f, 1.f, 1.f, 1.f}, sh = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float slope = g.in_act == DVAE_ACT_LRELU ? LRELU_SLOPE : 1.f;
-  if (XF) {
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      sc[u] = g.in_scale ? ldg4(g.in_scale + 16 * u + 4 * kq) : (f32x4){1.f, 1.f, 1.f, 1.f};
-      sh[u] = g.in_scale ? ldg4(g.in_shift + 16 * u + 4 * kq) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+  if (XF && g.in_scale) {
+    sc = ldg4(g.in_scale + 4 * lc4);
+    sh = ldg4(g.in_shift + 4 * lc4);
   }
-  // per-channel constants of the BatchNorm-backward sums, for this lane's output channels 16cb + 4kq + r
+  const int row_pieces = W * C4;
   f32x4 bsc[NCB], bsh[NCB], bmu[NCB], bis[NCB];
   if (BNS) {
 #pragma unroll
@@ -551,123 +556,129 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_stream_kernel(ConvAr
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) s1[cb] = s2[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // one group of sixteen positions: where its output pixel is, which taps are inside the frame
-  struct Group {
-    int64_t orow;
-    unsigned okbits;     // bit t: tap t inside the frame; bit 4: the position itself exists
-  };
-  // issue the loads of a group's tap pixels (raw) into xr
-  auto start = [&](int64_t grp, Group& gr, f32x4 (&xr)[4][NU]) {
-    const int64_t m = grp * 16 + i16;
-    const bool mok = m < g.M;
-    const int b = (int)(m & ((1 << g.lw) - 1));
-    const int a = (int)((m >> g.lw) & ((1 << g.lh) - 1));
-    const int64_t n = m >> (g.lw + g.lh);
-    gr.orow = (n * (2 * g.H) + (2 * a + ph)) * (2 * g.W) + (2 * b + pw);
-    gr.okbits = mok ? 16u : 0u;
+  // zero pixels left and right of every row slot
+  for (int i = threadIdx.x; i < 4 * 2 * PS; i += 256) {
+    const int slot = i / (2 * PS), r = i % (2 * PS);
+    ring[slot][(r < PS ? 0 : (W + 1) * PS) + r % PS] = 0.f;
+  }
+
+  // Rows are numbered over the whole batch (row = image * H + a): consecutive rows are consecutive in
+  // memory.  The grid has one workgroup per partial-statistics row the caller allocated; the first
+  // g.mtiles of them share out the rows in contiguous runs, the rest write zero statistics.
+  const int64_t rows = g.M >> g.lw;
+  const int64_t per = (rows + g.mtiles - 1) / g.mtiles;
+  const int64_t r0 = (int)blockIdx.x < g.mtiles ? blockIdx.x * per : rows;
+  const int64_t r1 = r0 + per < rows ? r0 + per : rows;
+
+  f32x4 raw[NLD];
+  auto fetch = [&](int64_t row) {            // issue the loads of a row (nothing if it does not exist)
+    const bool rok = row >= 0 && row < rows;
+    const float* src = g.x + (rok ? row : 0) * (int64_t)row_pieces * 4;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int hh = a + ph - (t >> 1), ww = b + pw - (t & 1);
-      const bool ok = mok && hh >= 0 && hh < g.H && ww >= 0 && ww < g.W;
-      gr.okbits |= (unsigned)ok << t;
-      // branch-free: a tap outside the frame reads the first pixel (and is zeroed later)
-      const int64_t off = (((n * g.H + hh) * g.W + ww) * CIN) & -(int64_t)ok;
-      const float* p = g.x + off + 4 * kq;
-#pragma unroll
-      for (int u = 0; u < NU; ++u) xr[t][u] = ldg4(p + 16 * u);
+    for (int j = 0; j < NLD; ++j) {
+      const int f = threadIdx.x + 256 * j;
+      raw[j] = ldg4(src + 4 * (rok && f < row_pieces ? f : 0));
     }
-    __builtin_amdgcn_sched_barrier(0);      // every load of the group is issued before what follows
   };
-  // multiply the group whose raw pixels are in xr (group descriptor cur)
-  auto finish = [&](const Group& cur, f32x4 (&xr)[4][NU]) {
-    // operands: transform of the producing layer, zero outside the frame
+  auto deposit = [&](int64_t row) {          // transform and write the fetched row into its slot
+    float* dst = ring[row & 3];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const bool keep = (cur.okbits >> t) & 1u;
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        f32x4 v = xr[t][u];
+    for (int j = 0; j < NLD; ++j) {
+      const int f = threadIdx.x + 256 * j;
+      if (f < row_pieces) {
+        f32x4 v = raw[j];
         if (XF) {
+          const f32x4 z = v * sc + sh;       // slope <= 1: lrelu(z) = max(z, slope z)
+          const f32x4 zs = z * slope;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(z[e], zs[e]);
+        }
+        *reinterpret_cast<f32x4*>(dst + (1 + f / C4) * PS + 4 * lc4) = v;
+      }
+    }
+  };
+  if (r0 < r1) {
+    fetch(r0 - 1);
+    deposit(r0 - 1);
+    fetch(r0);
+    deposit(r0);
+    fetch(r0 + 1);
+    deposit(r0 + 1);
+  }
+  __syncthreads();
+  for (int64_t r = r0; r < r1; ++r) {
+    fetch(r + 2);
+    const int a = (int)r & (H - 1);
+    for (int j = 0; j < W / 16; ++j) {
+      const int64_t orow = (2 * r + ph) * (2 * W) + 2 * (16 * j + i16) + pw;
+      f32x4 yv[NCB];
+      if (BNS) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) yv[cb] = ldg4(g.bn_y + orow * COUT + 16 * cb + 4 * kq);
+      }
+      f32x4 acc[NCB][2];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int th = 0; th < 2; ++th) {
+        const int arow = a + ph - th;
+        if (arow < 0 || arow >= H) continue;          // the tap row is above or below the frame
+        const float* rowp = ring[(r + ph - th) & 3];
+        f32x4 xv[2][NU];
+#pragma unroll
+        for (int tw = 0; tw < 2; ++tw)
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+            xv[tw][u] = *reinterpret_cast<const f32x4*>(rowp + (1 + 16 * j + i16 + pw - tw) * PS + 16 * u + 4 * kq);
+#pragma unroll
+        for (int tw = 0; tw < 2; ++tw)
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int cb = 0; cb < NCB; ++cb)
+                acc[cb][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][2 * th + tw][u][e], xv[tw][u][e],
+                                                                      acc[cb][e & 1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        // D: row = output channel 16cb + 4kq + r, column = pixel 16j + i16
+        const f32x4 v = acc[cb][0] + acc[cb][1];
+        *reinterpret_cast<f32x4*>(g.y + orow * COUT + 16 * cb + 4 * kq) = v;
+        if (!BNS) {
+          s1[cb] += v;
+          s2[cb] += v * v;
+        } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float z = fmaf(v[e], sc[u][e], sh[u][e]);
-            v[e] = z > 0.f ? z : z * slope;
+            const float z = fmaf(yv[cb][e], bsc[cb][e], bsh[cb][e]);
+            const float dz = z > 0.f ? v[e] : v[e] * LRELU_SLOPE;
+            s1[cb][e] += dz;
+            s2[cb][e] += dz * ((yv[cb][e] - bmu[cb][e]) * bis[cb][e]);
           }
         }
-        xr[t][u] = zero_unless(v, keep);
       }
     }
-    const bool mok = (cur.okbits >> 4) & 1u;
-    f32x4 yv[NCB];
-    if (BNS) {
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) yv[cb] = ldg4(g.bn_y + (mok ? cur.orow * COUT : 0) + 16 * cb + 4 * kq);
-    }
-    // two accumulators per channel block (taps 0,1 / 2,3): no MFMA waits for the one before it
-    f32x4 acc[NCB][2];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) acc[cb][0] = acc[cb][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int u = 0; u < NU; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int cb = 0; cb < NCB; ++cb)
-            acc[cb][t >> 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][t][u][e], xr[t][u][e], acc[cb][t >> 1], 0, 0, 0);
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-      // D: row = output channel 16cb + 4kq + r, column = position i16
-      const f32x4 v = acc[cb][0] + acc[cb][1];
-      if (mok) *reinterpret_cast<f32x4*>(g.y + cur.orow * COUT + 16 * cb + 4 * kq) = v;
-      if (!BNS) {
-        s1[cb] += v;          // positions past M multiply all-zero operands: they add nothing
-        s2[cb] += v * v;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float z = fmaf(yv[cb][r], bsc[cb][r], bsh[cb][r]);
-          const float dz = mok ? (z > 0.f ? v[r] : v[r] * LRELU_SLOPE) : 0.f;
-          s1[cb][r] += dz;
-          s2[cb][r] += dz * ((yv[cb][r] - bmu[cb][r]) * bis[cb][r]);
-        }
-      }
-    }
-  };
-
-  // The grid has one workgroup per partial-statistics row the caller allocated; only the first
-  // g.mtiles of them (as many as are resident at once) share out the work, the rest write zero rows.
-  // Two register buffers alternate: while one group is multiplied the next one's loads are in flight
-  // (past the end: a group with no positions, every load reads the first pixel, nothing is stored).
-  const int64_t ngroups = (g.M + 15) / 16;
-  const int64_t step = g.mtiles;
-  int64_t grp = (int)blockIdx.x < g.mtiles ? blockIdx.x : ngroups;
-  f32x4 xa[4][NU], xb[4][NU];
-  Group ga, gb;
-  if (grp < ngroups) start(grp, ga, xa);
-  for (; grp < ngroups; grp += 2 * step) {
-    start(grp + step, gb, xb);
-    finish(ga, xa);
-    start(grp + 2 * step, ga, xa);
-    finish(gb, xb);
+    deposit(r + 2);       // slot (r+2)&3 is not among the three this row reads
+    __syncthreads();
   }
   if (g.stats) {
-    // the sixteen lanes with equal kq hold different positions of the same channels
+    // the sixteen lanes with equal kq hold different pixels of the same channels
     const int64_t part = (int64_t)phase * gridDim.x + blockIdx.x;
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a1 = s1[cb][r], a2 = s2[cb][r];
+      for (int e = 0; e < 4; ++e) {
+        float a1 = s1[cb][e], a2 = s2[cb][e];
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) {
           a1 += __shfl_xor(a1, o);
           a2 += __shfl_xor(a2, o);
         }
         if (i16 == 0) {
-          g.stats[(part * 2 + 0) * COUT + 16 * cb + 4 * kq + r] = a1;
-          g.stats[(part * 2 + 1) * COUT + 16 * cb + 4 * kq + r] = a2;
+          g.stats[(part * 2 + 0) * COUT + 16 * cb + 4 * kq + e] = a1;
+          g.stats[(part * 2 + 1) * COUT + 16 * cb + 4 * kq + e] = a2;
         }
       }
   }
@@ -709,27 +720,27 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   typedef Tile<128, 128, 2, 2, true, true> T128;
   typedef Tile<128, 64, 4, 1, true, true> T64;
   typedef Tile<128, 32, 4, 1, true, true> T32;
-#define STREAM_LAUNCH(CI, CO, WPE, RESIDENT)                                                             \
-  if (MODE == 1 && !bf && g.Cin == CI && g.Cout == CO && aligned16(g.y) && (!bns || aligned16(g.bn_y)) && \
+#define ROWS_LAUNCH(CI, CO, WPE, RESIDENT)                                                               \
+  if (MODE == 1 && !bf && g.Cin == CI && g.Cout == CO && g.W >= 16 && g.W <= ROWS_WMAX &&                 \
+      aligned16(g.y) && (!bns || aligned16(g.bn_y)) &&                                                    \
       (!g.in_scale || (aligned16(g.in_scale) && aligned16(g.in_shift)))) {                                \
     const dim3 grid((unsigned)(conv_parts_written(g.M, phases) / phases));                                \
-    /* workgroups resident at once at the kernel's register count share out the work */                   \
     g.mtiles = (int)grid.x < 256 * RESIDENT ? (int)grid.x : 256 * RESIDENT;                               \
     const bool xf = g.in_scale != nullptr || g.in_act != DVAE_ACT_NONE;                                   \
     if (bns && xf)                                                                                        \
-      hipLaunchKernelGGL((deconv_stream_kernel<CI, CO, WPE, true, true>), grid, dim3(256), 0, stream, g); \
+      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, true, true>), grid, dim3(256), 0, stream, g);   \
     else if (bns)                                                                                         \
-      hipLaunchKernelGGL((deconv_stream_kernel<CI, CO, WPE, false, true>), grid, dim3(256), 0, stream, g); \
+      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, false, true>), grid, dim3(256), 0, stream, g);  \
     else if (xf)                                                                                          \
-      hipLaunchKernelGGL((deconv_stream_kernel<CI, CO, WPE, true, false>), grid, dim3(256), 0, stream, g); \
+      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, true, false>), grid, dim3(256), 0, stream, g);  \
     else                                                                                                  \
-      hipLaunchKernelGGL((deconv_stream_kernel<CI, CO, WPE, false, false>), grid, dim3(256), 0, stream, g); \
+      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, false, false>), grid, dim3(256), 0, stream, g); \
     DVAE_LAUNCH_CHECK(name);                                                                              \
     return 0;                                                                                             \
   }
-  STREAM_LAUNCH(32, 16, 2, 2)
-  STREAM_LAUNCH(64, 32, 1, 1)
-#undef STREAM_LAUNCH
+  ROWS_LAUNCH(32, 16, 2, 4)
+  ROWS_LAUNCH(64, 32, 2, 2)
+#undef ROWS_LAUNCH
   if (c1 && MODE == 0 && g.Cout <= 64 && aligned16(g.y) && (!bns || aligned16(g.bn_y))) {
     // one partial-statistics row per workgroup, as many rows as the caller sized the buffer for
     const dim3 grid((unsigned)conv_parts_written(g.M, 1));

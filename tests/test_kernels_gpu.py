@@ -216,10 +216,12 @@ def test_conv4s2_fwd(ops, N, H, Cin, Cout):
     assert rel_err(s[1], (ref ** 2).sum(dim=(0, 2, 3))) < 1e-5
 
 
-# (64,32) and (32,16) take the register-resident-filter kernel: partial groups of positions (H=2) and
-# more workgroups than are resident at once (the large N) are its edge cases
+# (64,32) and (32,16) on frames at least 16 wide take the row-ring kernel: one and two groups of
+# sixteen pixels per row (H=16, 32), a single row per image never (H >= 16), and more workgroups than
+# share out the rows (N=70 at 64->32); the same channels on smaller frames take the tiled kernel
 DECONV_CASES = [(3, 4, 64, 32), (2, 8, 32, 16), (3, 16, 16, 8), (2, 32, 8, 4), (6, 4, 256, 128), (70, 4, 4, 36),
-                (3, 2, 64, 32), (5, 2, 32, 16), (100, 32, 32, 16), (40, 32, 64, 32)]
+                (3, 2, 64, 32), (5, 2, 32, 16), (100, 32, 32, 16), (40, 32, 64, 32), (3, 16, 32, 16), (2, 16, 64, 32),
+                (300, 16, 32, 16), (70, 32, 64, 32)]
 
 
 @pytest.mark.parametrize('N,H,Cin,Cout', DECONV_CASES)
@@ -494,7 +496,8 @@ def test_device_rendered_batches_are_bit_identical(ops, kwargs, seed):
                                                ('deconv', 3, 4, 64, 32), ('deconv', 2, 8, 32, 16),
                                                ('deconv', 6, 4, 256, 128), ('deconv', 70, 4, 4, 36),
                                                ('deconv', 5, 2, 32, 16), ('deconv', 100, 32, 32, 16),
-                                               ('deconv', 40, 32, 64, 32)])
+                                               ('deconv', 40, 32, 64, 32), ('deconv', 3, 16, 32, 16),
+                                               ('deconv', 2, 16, 64, 32)])
 def test_dgrad_with_fused_bn_backward_statistics(ops, kind, N, H, Cin, Cout):
     """The data-gradient kernels with the BatchNorm-backward reduction folded into their epilogue: the
     gradient they write is the plain kernel's, the partial rows sum to sum(dz) and sum(dz*xhat), and
