@@ -111,6 +111,8 @@ class KernelTimer:
             if Cin == 1:        # sixteen taps deep: bound by the write of the output
                 return "conv_c1_kernel", float(x.numel() * 4 + N * (H // 2) * (W // 2) * Cout * 4), 'byte'
             fl = 2.0 * N * (H // 2) * (W // 2) * Cout * 16 * Cin
+            if (Cin, Cout) in ((32, 64), (16, 32)) and 32 <= W <= 64:     # few channels: rows through an LDS ring
+                return f"conv_rows_kernel<{Cin},{Cout}>", fl, 'flop'
             return f"conv_fwd_kernel<{tile(Cout)},conv>", fl, 'flop'
 
         def conv_bn_key(x, wp, bn_y, aff):

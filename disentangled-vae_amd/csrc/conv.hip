@@ -684,6 +684,172 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
   }
 }
 
+// Stride-2 convolution with few channels (Cin <= 32) on frames at least 32 pixels wide, by the same
+// scheme: a wave keeps the filter of sixteen output channels [16][16 taps][Cin] in registers (the
+// workgroup has Cout/16 waves), input rows go through an LDS ring once (eight slots: four rows feed an
+// output row, two more are in flight), and the output row's sixteen-pixel groups take their B operands
+// from LDS.  A row slot holds the even and the odd input columns apart, so that the sixteen lanes of a
+// read (output pixels ob..ob+15, input column 2ob-1+kw) touch consecutive pixels: the odd columns are
+// preceded by a zero pixel (column -1) and the even ones followed by one (column W).
+template <int CIN, int COUT, int WAVES_PER_EU, bool XF, bool BNS>
+__global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvArgs g) {
+  constexpr int NU = CIN / 16, NT = COUT * 4;
+  constexpr int PS = CIN + 4;                       // pixel stride in LDS: 16-byte reads without bank conflicts
+  constexpr int C4 = CIN / 4;                       // 16-byte pieces per pixel
+  constexpr int NLD = (64 * C4 + NT - 1) / NT;      // 16-byte pieces of a row per thread, at most (W <= 64)
+  extern __shared__ __attribute__((aligned(16))) float ring[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int W = g.W, H = g.H, Wo = W >> 1, Ho = H >> 1;
+  const int half = Wo + 1;                          // pixels of one parity, with its zero pixel
+  const int slot_floats = 2 * half * PS;
+  // component m of wa[t][u] multiplies channel 16u + 4kq + m of tap t into output channel 16 wave + i16
+  f32x4 wa[16][NU];
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      wa[t][u] = ldg4(g.wp + ((int64_t)(16 * wave + i16) * 16 + t) * CIN + 16 * u + 4 * kq);
+  const int lc4 = threadIdx.x % C4;
+  f32x4 sc = (f32x4){1.f, 1.f, 1.f, 1.f}, sh = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float slope = g.in_act == DVAE_ACT_LRELU ? LRELU_SLOPE : 1.f;
+  if (XF && g.in_scale) {
+    sc = ldg4(g.in_scale + 4 * lc4);
+    sh = ldg4(g.in_shift + 4 * lc4);
+  }
+  const int row_pieces = W * C4;
+  f32x4 bsc, bsh, bmu, bis;
+  if (BNS) {
+    bsc = ldg4(g.bn_scale + 16 * wave + 4 * kq);
+    bsh = ldg4(g.bn_shift + 16 * wave + 4 * kq);
+    bmu = ldg4(g.bn_mean + 16 * wave + 4 * kq);
+    bis = ldg4(g.bn_invstd + 16 * wave + 4 * kq);
+  }
+  f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // the zero pixels of every slot: even columns' at index Wo, odd columns' at index 0 of their half
+  for (int i = threadIdx.x; i < 8 * 2 * PS; i += NT) {
+    const int slot = i / (2 * PS), r = i % (2 * PS);
+    ring[slot * slot_floats + (r < PS ? Wo * PS : half * PS) + r % PS] = 0.f;
+  }
+
+  // Output rows are numbered over the whole batch (row = image * Ho + oa); output row r reads input
+  // rows 2r-1 .. 2r+2 of the same numbering.  The grid has one workgroup per partial-statistics row
+  // the caller allocated; the first g.mtiles share out the rows in contiguous runs.
+  const int64_t rows = g.M >> g.lw, rows_in = 2 * rows;
+  const int64_t per = (rows + g.mtiles - 1) / g.mtiles;
+  const int64_t r0 = (int)blockIdx.x < g.mtiles ? blockIdx.x * per : rows;
+  const int64_t r1 = r0 + per < rows ? r0 + per : rows;
+
+  auto fetch = [&](int64_t row, f32x4 (&raw)[NLD]) {      // issue the loads of an input row (if it exists)
+    const bool rok = row >= 0 && row < rows_in;
+    const float* src = g.x + (rok ? row : 0) * (int64_t)row_pieces * 4;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int f = threadIdx.x + NT * j;
+      raw[j] = ldg4(src + 4 * (rok && f < row_pieces ? f : 0));
+    }
+  };
+  auto deposit = [&](int64_t row, const f32x4 (&raw)[NLD]) {   // transform, split by column parity, store
+    float* dst = ring + (row & 7) * slot_floats;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int f = threadIdx.x + NT * j;
+      if (f < row_pieces) {
+        f32x4 v = raw[j];
+        if (XF) {
+          const f32x4 z = v * sc + sh;       // slope <= 1: lrelu(z) = max(z, slope z)
+          const f32x4 zs = z * slope;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(z[e], zs[e]);
+        }
+        const int px = f / C4;
+        const int at = (px & 1) ? half + 1 + (px >> 1) : (px >> 1);
+        *reinterpret_cast<f32x4*>(dst + at * PS + 4 * lc4) = v;
+      }
+    }
+  };
+  f32x4 rawa[NLD], rawb[NLD];
+  if (r0 < r1) {
+    fetch(2 * r0 - 1, rawa);
+    fetch(2 * r0, rawb);
+    deposit(2 * r0 - 1, rawa);
+    deposit(2 * r0, rawb);
+    fetch(2 * r0 + 1, rawa);
+    fetch(2 * r0 + 2, rawb);
+    deposit(2 * r0 + 1, rawa);
+    deposit(2 * r0 + 2, rawb);
+  }
+  __syncthreads();
+  for (int64_t r = r0; r < r1; ++r) {
+    fetch(2 * r + 3, rawa);
+    fetch(2 * r + 4, rawb);
+    const int oa = (int)r & (Ho - 1);
+    for (int j = 0; j < Wo / 16; ++j) {
+      const int ob = 16 * j + i16;
+      const int64_t orow = r * Wo + ob;
+      f32x4 yv;
+      if (BNS) yv = ldg4(g.bn_y + orow * COUT + 16 * wave + 4 * kq);
+      f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kh = 0; kh < 4; ++kh) {
+        const int hin = 2 * oa - 1 + kh;
+        if (hin < 0 || hin >= H) continue;          // the tap row is above or below the frame
+        const float* rowp = ring + ((2 * r - 1 + kh) & 7) * slot_floats;
+        // input column 2ob-1+kw: kw 0 -> odd[ob-1], 1 -> even[ob], 2 -> odd[ob], 3 -> even[ob+1]
+        const int at[4] = {half + ob, ob, half + ob + 1, ob + 1};
+        f32x4 xv[4][NU];
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+            xv[kw][u] = *reinterpret_cast<const f32x4*>(rowp + at[kw] * PS + 16 * u + 4 * kq);
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[4 * kh + kw][u][e], xv[kw][u][e], acc[e & 1], 0, 0, 0);
+      }
+      // D: row = output channel 16 wave + 4kq + e, column = output pixel ob
+      const f32x4 v = acc[0] + acc[1];
+      *reinterpret_cast<f32x4*>(g.y + orow * COUT + 16 * wave + 4 * kq) = v;
+      if (!BNS) {
+        s1 += v;
+        s2 += v * v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = fmaf(yv[e], bsc[e], bsh[e]);
+          const float dz = z > 0.f ? v[e] : v[e] * LRELU_SLOPE;
+          s1[e] += dz;
+          s2[e] += dz * ((yv[e] - bmu[e]) * bis[e]);
+        }
+      }
+    }
+    deposit(2 * r + 3, rawa);       // slots of rows 2r+3, 2r+4 are not among the four this row reads
+    deposit(2 * r + 4, rawb);
+    __syncthreads();
+  }
+  if (g.stats) {
+    // the sixteen lanes with equal kq hold different pixels of the same channels
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a1 = s1[e], a2 = s2[e];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        a1 += __shfl_xor(a1, o);
+        a2 += __shfl_xor(a2, o);
+      }
+      if (i16 == 0) {
+        g.stats[((int64_t)blockIdx.x * 2 + 0) * COUT + 16 * wave + 4 * kq + e] = a1;
+        g.stats[((int64_t)blockIdx.x * 2 + 1) * COUT + 16 * wave + 4 * kq + e] = a2;
+      }
+    }
+  }
+}
+
 extern "C" int64_t dvae_conv_stat_parts(int64_t M_rows) {
   (void)M_rows;
   return 4 * CONV_MAX_PARTS;
@@ -741,6 +907,28 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   ROWS_LAUNCH(32, 16, 2, 4)
   ROWS_LAUNCH(64, 32, 2, 2)
 #undef ROWS_LAUNCH
+#define CONV_ROWS_LAUNCH(CI, CO, WPE, RESIDENT)                                                           \
+  if (MODE == 0 && !bf && g.Cin == CI && g.Cout == CO && g.W >= 32 && g.W <= 64 && g.H >= 2 &&            \
+      aligned16(g.y) && (!bns || aligned16(g.bn_y)) &&                                                    \
+      (!g.in_scale || (aligned16(g.in_scale) && aligned16(g.in_shift)))) {                                \
+    const dim3 grid((unsigned)conv_parts_written(g.M, 1));                                                \
+    g.mtiles = (int)grid.x < 256 * RESIDENT ? (int)grid.x : 256 * RESIDENT;                               \
+    const size_t lds = (size_t)8 * 2 * (g.W / 2 + 1) * (CI + 4) * sizeof(float);                          \
+    const bool xf = g.in_scale != nullptr || g.in_act != DVAE_ACT_NONE;                                   \
+    if (bns && xf)                                                                                        \
+      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, true, true>), grid, dim3(CO * 4), lds, stream, g); \
+    else if (bns)                                                                                         \
+      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, false, true>), grid, dim3(CO * 4), lds, stream, g); \
+    else if (xf)                                                                                          \
+      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, true, false>), grid, dim3(CO * 4), lds, stream, g); \
+    else                                                                                                  \
+      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, false, false>), grid, dim3(CO * 4), lds, stream, g); \
+    DVAE_LAUNCH_CHECK(name);                                                                              \
+    return 0;                                                                                             \
+  }
+  CONV_ROWS_LAUNCH(32, 64, 2, 2)
+  CONV_ROWS_LAUNCH(16, 32, 2, 4)
+#undef CONV_ROWS_LAUNCH
   if (c1 && MODE == 0 && g.Cout <= 64 && aligned16(g.y) && (!bns || aligned16(g.bn_y))) {
     // one partial-statistics row per workgroup, as many rows as the caller sized the buffer for
     const dim3 grid((unsigned)conv_parts_written(g.M, 1));

@@ -195,6 +195,9 @@ def nchw(t):
 CONV_CASES = [  # N, H, Cin, Cout
     (3, 64, 1, 16), (2, 64, 1, 32), (5, 32, 16, 32), (3, 16, 32, 64), (4, 8, 64, 128), (9, 4, 8, 4),
     (2, 8, 128, 256), (130, 4, 4, 8),
+    # (32,64) and (16,32) on frames at least 32 wide take the row-ring kernel: one and two groups of
+    # sixteen output pixels per row, more workgroups than share out the rows (N=300)
+    (4, 32, 32, 64), (3, 64, 16, 32), (2, 64, 32, 64), (300, 32, 32, 64), (37, 32, 16, 32),
 ]
 
 
@@ -492,6 +495,7 @@ def test_device_rendered_batches_are_bit_identical(ops, kwargs, seed):
 
 # ------------------------------------------------------------------ data gradient + BatchNorm-backward statistics
 @pytest.mark.parametrize('kind,N,H,Cin,Cout', [('conv', 5, 32, 16, 32), ('conv', 3, 64, 1, 16), ('conv', 3, 64, 1, 32),
+                                               ('conv', 4, 32, 32, 64), ('conv', 2, 64, 32, 64),
                                                ('conv', 2, 8, 128, 256), ('conv', 70, 4, 4, 36),
                                                ('deconv', 3, 4, 64, 32), ('deconv', 2, 8, 32, 16),
                                                ('deconv', 6, 4, 256, 128), ('deconv', 70, 4, 4, 36),

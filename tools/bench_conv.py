@@ -38,7 +38,7 @@ def main():
     ops.set_precision(a.precision)
     dev = 'cuda'
     # (Cin, Cout, H_in of the transposed conv)
-    layers = [(256, 128, 4), (128, 64, 8), (64, 32, 16), (32, 16, 16)]
+    layers = [(256, 128, 4), (128, 64, 8), (64, 32, 16), (32, 16, 16)]     # last: the motion encoder's second layer
     rows = []
     for Cin, Cout, H in layers:
         x = torch.randn(N, H, H, Cin, device=dev)
