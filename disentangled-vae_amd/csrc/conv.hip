@@ -1313,13 +1313,190 @@ wgrad_reduce_kernel(const float* __restrict__ slab, int split, float* __restrict
   }
 }
 
+// Weight gradient with few channels (C1*C2 <= 2048): the whole gradient [C1][16 taps][C2] fits in the
+// accumulators of one workgroup, so a workgroup keeps it there and streams a contiguous run of P rows
+// past it (K = pixels).  Rows of P and of Q go through LDS rings once, in their memory layout
+// [pixel][channel] with the producing layers' transforms applied on the way in; a lane reads its MFMA
+// operands with 4-byte LDS reads (A: P[pixel 4kq+e][c1], B: Q[pixel of the tap][c2], pixel strides
+// chosen so that the four pixel quads of a read fall into different banks), the zero pixels left and
+// right of every Q row stand for the frame's edges, and taps above/below the frame are skipped.  Wave
+// w owns the sixteen rows 16 (w % NRB) of the gradient and an equal share of the taps.  Each workgroup
+// writes its partial gradient as one slab for wgrad_reduce_kernel.
+template <int C1, int C2, int WAVES_PER_EU, bool XP, bool XQ>
+__global__ void __launch_bounds__(256, WAVES_PER_EU) wgrad_rows_kernel(WgradArgs g) {
+  constexpr int NRB = C1 / 16;            // row blocks of the gradient
+  constexpr int CPARTS = 4 / NRB;         // the taps are shared between this many waves per row block
+  constexpr int DHN = 4 / CPARTS;         // filter rows per wave
+  constexpr int NCB = C2 / 16;
+  constexpr int PSP = C1 + 4, PSQ = C2 + 2;
+  constexpr int P4 = C1 / 4, Q4 = C2 / 4;
+  constexpr int NLP = (32 * P4 + 255) / 256, NLQ = (64 * Q4 + 255) / 256;   // Ws <= 32
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int Ws = g.Ws, Hs = g.Hs, WQ = 2 * Ws;
+  const int pslot = Ws * PSP, qslot = (WQ + 2) * PSQ;
+  float* const pring = lds;                // 4 slots
+  float* const qring = lds + 4 * pslot;    // 8 slots
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int rb = wave % NRB, dh0 = (wave / NRB) * DHN;
+
+  const int lp4 = threadIdx.x % P4, lq4 = threadIdx.x % Q4;
+  f32x4 psc = (f32x4){1.f, 1.f, 1.f, 1.f}, psh = (f32x4){0.f, 0.f, 0.f, 0.f}, qsc = psc, qsh = psh;
+  const float pslope = g.p_act == DVAE_ACT_LRELU ? LRELU_SLOPE : 1.f;
+  const float qslope = g.q_act == DVAE_ACT_LRELU ? LRELU_SLOPE : 1.f;
+  if (XP && g.p_scale) {
+    psc = ldg4(g.p_scale + 4 * lp4);
+    psh = ldg4(g.p_shift + 4 * lp4);
+  }
+  if (XQ && g.q_scale) {
+    qsc = ldg4(g.q_scale + 4 * lq4);
+    qsh = ldg4(g.q_shift + 4 * lq4);
+  }
+  // zero pixels left (column -1) and right (column WQ) of every Q slot
+  for (int i = threadIdx.x; i < 8 * 2 * PSQ; i += 256) {
+    const int slot = i / (2 * PSQ), r = i % (2 * PSQ);
+    qring[slot * qslot + (r < PSQ ? 0 : (WQ + 1) * PSQ) + r % PSQ] = 0.f;
+  }
+
+  f32x4 acc[DHN][4][NCB];
+#pragma unroll
+  for (int a = 0; a < DHN; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // P rows are numbered over the whole batch (row = image * Hs + a); P row r meets Q rows 2r-1 .. 2r+2
+  const int64_t rows = g.Mtot >> g.lw, qrows = 2 * rows;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = blockIdx.x * per;
+  const int64_t r1 = r0 + per < rows ? r0 + per : rows;
+  const int p_pieces = Ws * P4, q_pieces = WQ * Q4;
+
+  auto transform = [](f32x4 v, const f32x4& sc, const f32x4& sh, float slope) {
+    const f32x4 z = v * sc + sh;         // slope <= 1: lrelu(z) = max(z, slope z)
+    const f32x4 zs = z * slope;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(z[e], zs[e]);
+    return v;
+  };
+  auto fetch_p = [&](int64_t row, f32x4 (&raw)[NLP]) {
+    const bool rok = row >= 0 && row < rows;
+    const float* src = g.P + (rok ? row : 0) * (int64_t)p_pieces * 4;
+#pragma unroll
+    for (int j = 0; j < NLP; ++j) {
+      const int f = threadIdx.x + 256 * j;
+      raw[j] = ldg4(src + 4 * (rok && f < p_pieces ? f : 0));
+    }
+  };
+  auto deposit_p = [&](int64_t row, const f32x4 (&raw)[NLP]) {
+    float* dst = pring + (row & 3) * pslot;
+#pragma unroll
+    for (int j = 0; j < NLP; ++j) {
+      const int f = threadIdx.x + 256 * j;
+      if (f < p_pieces) {
+        const f32x4 v = XP ? transform(raw[j], psc, psh, pslope) : raw[j];
+        *reinterpret_cast<f32x4*>(dst + (f / P4) * PSP + 4 * lp4) = v;
+      }
+    }
+  };
+  auto fetch_q = [&](int64_t row, f32x4 (&raw)[NLQ]) {
+    const bool rok = row >= 0 && row < qrows;
+    const float* src = g.Q + (rok ? row : 0) * (int64_t)q_pieces * 4;
+#pragma unroll
+    for (int j = 0; j < NLQ; ++j) {
+      const int f = threadIdx.x + 256 * j;
+      raw[j] = ldg4(src + 4 * (rok && f < q_pieces ? f : 0));
+    }
+  };
+  auto deposit_q = [&](int64_t row, const f32x4 (&raw)[NLQ]) {
+    float* dst = qring + (row & 7) * qslot;
+#pragma unroll
+    for (int j = 0; j < NLQ; ++j) {
+      const int f = threadIdx.x + 256 * j;
+      if (f < q_pieces) {
+        const f32x4 v = XQ ? transform(raw[j], qsc, qsh, qslope) : raw[j];
+        float* d = dst + (1 + f / Q4) * PSQ + 4 * lq4;       // 8-byte aligned (PSQ is even)
+        *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
+        *reinterpret_cast<float2*>(d + 2) = make_float2(v[2], v[3]);
+      }
+    }
+  };
+  f32x4 rawp[NLP], rawq0[NLQ], rawq1[NLQ];
+  if (r0 < r1) {
+    fetch_p(r0, rawp);
+    fetch_q(2 * r0 - 1, rawq0);
+    fetch_q(2 * r0, rawq1);
+    deposit_p(r0, rawp);
+    deposit_q(2 * r0 - 1, rawq0);
+    deposit_q(2 * r0, rawq1);
+    fetch_q(2 * r0 + 1, rawq0);
+    fetch_q(2 * r0 + 2, rawq1);
+    deposit_q(2 * r0 + 1, rawq0);
+    deposit_q(2 * r0 + 2, rawq1);
+  }
+  __syncthreads();
+  for (int64_t r = r0; r < r1; ++r) {
+    fetch_p(r + 1, rawp);
+    fetch_q(2 * r + 3, rawq0);
+    fetch_q(2 * r + 4, rawq1);
+    const int a = (int)r & (Hs - 1);
+    const float* prow = pring + (r & 3) * pslot;
+    for (int j = 0; j < Ws / 16; ++j) {
+      const int b0 = 16 * j + 4 * kq;              // this lane's pixels are b0 + e
+      float av[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) av[e] = prow[(b0 + e) * PSP + 16 * rb + i16];
+#pragma unroll
+      for (int dl = 0; dl < DHN; ++dl) {
+        const int dh = dh0 + dl, hin = 2 * a - 1 + dh;
+        if (hin < 0 || hin >= 2 * Hs) continue;    // the tap row is above or below the frame
+        const float* qrow = qring + ((2 * r - 1 + dh) & 7) * qslot;
+        // Q pixel of (b, dw) is column 2b-1+dw, stored at index 2b+dw
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float bv[4][NCB];
+#pragma unroll
+          for (int dw = 0; dw < 4; ++dw)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) bv[dw][cb] = qrow[(2 * (b0 + e) + dw) * PSQ + 16 * cb + i16];
+#pragma unroll
+          for (int dw = 0; dw < 4; ++dw)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+              acc[dl][dw][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[dw][cb], acc[dl][dw][cb], 0, 0, 0);
+        }
+      }
+    }
+    deposit_p(r + 1, rawp);
+    deposit_q(2 * r + 3, rawq0);
+    deposit_q(2 * r + 4, rawq1);
+    __syncthreads();
+  }
+  // D: row = c1 16rb + 4kq + e, column = c2 16cb + i16 of tap 4dh + dw
+  float* slab = g.slab + (int64_t)blockIdx.x * C1 * g.NC;
+#pragma unroll
+  for (int dl = 0; dl < DHN; ++dl)
+#pragma unroll
+    for (int dw = 0; dw < 4; ++dw)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          slab[(int64_t)(16 * rb + 4 * kq + e) * g.NC + (4 * (dh0 + dl) + dw) * C2 + 16 * cb + i16] = acc[dl][dw][cb][e];
+}
+
 struct WgradPlan {
-  int bm;       // 32, 64 or 128; 0 = single-channel streaming kernel
+  int bm;       // 32, 64 or 128; 0 = single-channel streaming kernel; -1 = row-ring kernel (few channels)
   int64_t tm, tn;
   int split, ktiles_per_split;
 };
 
-static WgradPlan wgrad_plan(int64_t Mtot, int64_t C1, int64_t C2) {
+static bool wgrad_rows_shape(int64_t C1, int64_t C2, int64_t Ws) {
+  return ((C1 == 64 && C2 == 32) || (C1 == 32 && C2 == 16)) && (Ws == 16 || Ws == 32);
+}
+
+static WgradPlan wgrad_plan(int64_t Mtot, int64_t Ws, int64_t C1, int64_t C2) {
   WgradPlan p;
   if (C2 == 1 && C1 <= 16 * WG1_MAX_CB) {
     p.bm = 0;
@@ -1328,6 +1505,15 @@ static WgradPlan wgrad_plan(int64_t Mtot, int64_t C1, int64_t C2) {
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     p.split = (int)blocks;
+    p.ktiles_per_split = 0;
+    return p;
+  }
+  if (wgrad_rows_shape(C1, C2, Ws) && dvae_mfma_precision() == DVAE_PRECISION_F32) {
+    // one slab per workgroup; as many workgroups as are resident at once
+    p.bm = -1;
+    p.tm = p.tn = 1;
+    const int64_t rows = Mtot / Ws, resident = 256 * (C1 == 64 ? 2 : 4);
+    p.split = (int)(rows < resident ? rows : resident);
     p.ktiles_per_split = 0;
     return p;
   }
@@ -1346,7 +1532,7 @@ static WgradPlan wgrad_plan(int64_t Mtot, int64_t C1, int64_t C2) {
 }
 
 extern "C" int64_t dvae_conv_wgrad_ws_floats(int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2) {
-  const WgradPlan p = wgrad_plan(N * Hs * Ws, C1, C2);
+  const WgradPlan p = wgrad_plan(N * Hs * Ws, Ws, C1, C2);
   return (int64_t)p.split * C1 * C2 * 16;
 }
 
@@ -1368,10 +1554,25 @@ extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, cons
   g.Q = Q; g.q_scale = q_scale; g.q_shift = q_shift; g.q_act = q_act;
   g.slab = ws; g.Mtot = N * Hs * Ws; g.Hs = (int)Hs; g.Ws = (int)Ws; g.lh = ilog2(Hs); g.lw = ilog2(Ws);
   g.C1 = (int)C1; g.C2 = (int)C2; g.NC = (int)(16 * C2);
-  const WgradPlan p = wgrad_plan(g.Mtot, C1, C2);
+  const WgradPlan p = wgrad_plan(g.Mtot, Ws, C1, C2);
   g.ktiles_per_split = p.ktiles_per_split;
   hipStream_t s = ST(stream);
-  if (p.bm == 0) {
+  if (p.bm == -1) {
+    DVAE_REQUIRE((!p_scale || (aligned16(p_scale) && aligned16(p_shift))) && (!q_scale || (aligned16(q_scale) && aligned16(q_shift))),
+                 "conv4s2_wgrad: scale/shift vectors must be 16-byte aligned");
+    const dim3 grid((unsigned)p.split);
+    const bool xp = p_scale != nullptr || p_act != DVAE_ACT_NONE, xq = q_scale != nullptr || q_act != DVAE_ACT_NONE;
+#define WGR_LAUNCH(A, B)                                                                                  \
+  {                                                                                                       \
+    const size_t ldsb = (size_t)(4 * Ws * (A + 4) + 8 * (2 * Ws + 2) * (B + 2)) * sizeof(float);          \
+    if (xp && xq) hipLaunchKernelGGL((wgrad_rows_kernel<A, B, 2, true, true>), grid, dim3(256), ldsb, s, g);        \
+    else if (xp) hipLaunchKernelGGL((wgrad_rows_kernel<A, B, 2, true, false>), grid, dim3(256), ldsb, s, g);        \
+    else if (xq) hipLaunchKernelGGL((wgrad_rows_kernel<A, B, 2, false, true>), grid, dim3(256), ldsb, s, g);        \
+    else hipLaunchKernelGGL((wgrad_rows_kernel<A, B, 2, false, false>), grid, dim3(256), ldsb, s, g);               \
+  }
+    if (C1 == 64) WGR_LAUNCH(64, 32) else WGR_LAUNCH(32, 16)
+#undef WGR_LAUNCH
+  } else if (p.bm == 0) {
     const int ncb = (int)((C1 + 15) / 16);
     const dim3 grid((unsigned)p.split);
     if (ncb <= 1) hipLaunchKernelGGL((conv_wgrad_c1_kernel<1, 8>), grid, dim3(256), 0, s, g);

@@ -258,8 +258,10 @@ def test_deconv_is_conv_data_gradient(ops):
     assert rel_err(nchw(got), dx) < 2e-6
 
 
+# (64,32) and (32,16) with Ws 16 or 32 take the row-ring kernel (several rows per workgroup at N=300)
 WGRAD_CASES = [(3, 32, 16, 1), (4, 16, 32, 16), (3, 8, 64, 32), (2, 4, 128, 64), (5, 32, 32, 1), (2, 4, 8, 4),
-               (40, 16, 16, 8), (3, 2, 256, 128)]
+               (40, 16, 16, 8), (3, 2, 256, 128), (3, 16, 64, 32), (2, 32, 32, 16), (2, 32, 64, 32), (300, 16, 64, 32),
+               (70, 16, 32, 16)]
 
 
 @pytest.mark.parametrize('N,Hs,C1,C2', WGRAD_CASES)
@@ -279,9 +281,9 @@ def test_conv4s2_wgrad(ops, N, Hs, C1, C2):
     assert rel_err(got, dw) < 5e-6
 
 
-def test_wgrad_for_transposed_conv(ops):
+@pytest.mark.parametrize('N,H,Cin,Cout', [(3, 8, 16, 8), (3, 16, 64, 32), (2, 16, 32, 16)])
+def test_wgrad_for_transposed_conv(ops, N, H, Cin, Cout):
     # ConvTranspose2d weight gradient: P = layer input (with load transform), Q = dY
-    N, H, Cin, Cout = 3, 8, 16, 8
     x = rnd(N, Cin, H, H, seed=35)
     sc, sh = 1 + 0.3 * rnd(Cin, seed=36), 0.2 * rnd(Cin, seed=37)
     xin = O.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None])

@@ -27,6 +27,9 @@ def bench_label(name):
     m = re.match(r'void conv_c1_kernel<\d+, (true|false)>', name)
     if m:
         return 'conv_c1_kernel' + (',bnstat' if m.group(1) == 'true' else '')
+    m = re.match(r'void wgrad_rows_kernel<(\d+), (\d+),', name)
+    if m:
+        return f'wgrad_rows_kernel<{m.group(1)},{m.group(2)}>'
     m = re.match(r'void conv_wgrad_kernel<Tile<(\d+), (\d+), .*?>, (true|false)>', name)
     if m:
         return f'conv_wgrad_kernel<T{m.group(1)}x{m.group(2)}>'
