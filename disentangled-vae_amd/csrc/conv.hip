@@ -887,7 +887,7 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   typedef Tile<128, 64, 4, 1, true, true> T64;
   typedef Tile<128, 32, 4, 1, true, true> T32;
 #define ROWS_LAUNCH(CI, CO, WPE, RESIDENT)                                                               \
-  if (MODE == 1 && !bf && g.Cin == CI && g.Cout == CO && g.W >= 16 && g.W <= ROWS_WMAX &&                 \
+  if (MODE == 1 && g.Cin == CI && g.Cout == CO && g.W >= 16 && g.W <= ROWS_WMAX &&                 \
       aligned16(g.y) && (!bns || aligned16(g.bn_y)) &&                                                    \
       (!g.in_scale || (aligned16(g.in_scale) && aligned16(g.in_shift)))) {                                \
     const dim3 grid((unsigned)(conv_parts_written(g.M, phases) / phases));                                \
@@ -904,6 +904,8 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     DVAE_LAUNCH_CHECK(name);                                                                              \
     return 0;                                                                                             \
   }
+  // (in bf16 mode as well: at these sizes exact fp32 operands out of the row ring beat the tiled
+  // bf16 kernel)
   ROWS_LAUNCH(32, 16, 2, 4)
   ROWS_LAUNCH(64, 32, 2, 2)
 #undef ROWS_LAUNCH
@@ -1295,22 +1297,41 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(WgradArgs g) {
 
 // dw[(c1*C2 + c2)*16 + tap] = sum_z slab[z][c1][tap*C2 + c2]; threads walk the slab layout so the
 // reads of every slab are contiguous
+// Sum of the partial gradients.  Thread -> one gradient element (consecutive threads read consecutive
+// floats of a slab), blockIdx.y -> a run of `zchunk` slabs.  With one run the sums go to dw in the torch
+// layout; with several (many slabs of a small gradient: a single run would be one long chain of
+// dependent loads in a handful of threads) each run leaves a slab-shaped partial in `part`, and a
+// second launch over those finishes.  The order of the additions is fixed either way.
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float* __restrict__ slab, int split, float* __restrict__ dw, int64_t C1, int64_t C2) {
+wgrad_reduce_kernel(const float* __restrict__ slab, int split, int zchunk, float* __restrict__ part,
+                    float* __restrict__ dw, int64_t C1, int64_t C2) {
   const int64_t total = C1 * C2 * 16;
+  const int z0 = (int)blockIdx.y * zchunk, z1 = z0 + zchunk < split ? z0 + zchunk : split;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t c2 = i % C2, tap = (i / C2) & 15, c1 = i / (16 * C2);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int z = 0;
-    for (; z + 4 <= split; z += 4) {
+    int z = z0;
+    for (; z + 4 <= z1; z += 4) {
       s0 += slab[(int64_t)z * total + i];
       s1 += slab[(int64_t)(z + 1) * total + i];
       s2 += slab[(int64_t)(z + 2) * total + i];
       s3 += slab[(int64_t)(z + 3) * total + i];
     }
-    for (; z < split; ++z) s0 += slab[(int64_t)z * total + i];
-    dw[(c1 * C2 + c2) * 16 + tap] = (s0 + s1) + (s2 + s3);
+    for (; z < z1; ++z) s0 += slab[(int64_t)z * total + i];
+    const float v = (s0 + s1) + (s2 + s3);
+    if (gridDim.y == 1) {
+      const int64_t c2 = i % C2, tap = (i / C2) & 15, c1 = i / (16 * C2);
+      dw[(c1 * C2 + c2) * 16 + tap] = v;
+    } else {
+      part[(int64_t)blockIdx.y * total + i] = v;
+    }
   }
+}
+
+// slabs per run of the first stage (0: a single stage), and the number of runs
+#define WGRAD_REDUCE_RUNS 32
+static int wgrad_reduce_runs(int split, int64_t total) {
+  // worth it when the single-stage launch would have few threads and long chains
+  return (split >= 128 && total <= 65536) ? WGRAD_REDUCE_RUNS : 1;
 }
 
 // Weight gradient with few channels (C1*C2 <= 2048): the whole gradient [C1][16 taps][C2] fits in the
@@ -1533,7 +1554,9 @@ static WgradPlan wgrad_plan(int64_t Mtot, int64_t Ws, int64_t C1, int64_t C2) {
 
 extern "C" int64_t dvae_conv_wgrad_ws_floats(int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2) {
   const WgradPlan p = wgrad_plan(N * Hs * Ws, Ws, C1, C2);
-  return (int64_t)p.split * C1 * C2 * 16;
+  // the slabs, then the partial sums of a two-stage reduction
+  const int runs = wgrad_reduce_runs(p.split, C1 * C2 * 16);
+  return ((int64_t)p.split + (runs > 1 ? runs : 0)) * C1 * C2 * 16;
 }
 
 extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, const float* p_shift, int p_act,
@@ -1600,7 +1623,18 @@ extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, cons
   DVAE_LAUNCH_CHECK("conv4s2_wgrad");
   int64_t nb = ceil_div64(C1 * C2 * 16, 256);
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float*)ws, p.split, dw, C1, C2);
+  const int runs = wgrad_reduce_runs(p.split, C1 * C2 * 16);
+  if (runs > 1) {
+    float* part = ws + (int64_t)p.split * C1 * C2 * 16;
+    const int zchunk = (p.split + runs - 1) / runs, nruns = (p.split + zchunk - 1) / zchunk;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nb, (unsigned)nruns), dim3(256), 0, s, (const float*)ws,
+                       p.split, zchunk, part, dw, C1, C2);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nb, 1), dim3(256), 0, s, (const float*)part, nruns, nruns,
+                       part, dw, C1, C2);
+  } else {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nb, 1), dim3(256), 0, s, (const float*)ws, p.split, p.split,
+                       ws, dw, C1, C2);
+  }
   DVAE_LAUNCH_CHECK("conv4s2_wgrad_reduce");
   return 0;
 }

@@ -301,24 +301,42 @@ extern "C" int dvae_reparam_bwd_f32(const float* dz, const float* logvar, const 
   return 0;
 }
 
-__global__ void __launch_bounds__(256)
+// One workgroup of 1024 threads (the sums are two numbers; a second launch to combine partials would
+// cost more than it saves), four independent partial sums per thread so that the loads overlap.
+__global__ void __launch_bounds__(1024)
 kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, float* __restrict__ out, int64_t B,
               int64_t D, float free_bits) {
-  __shared__ double red[4];
-  double s_floor = 0.0, s_raw = 0.0;
+  __shared__ double red[2][16];
+  double s_floor[4] = {0.0, 0.0, 0.0, 0.0}, s_raw[4] = {0.0, 0.0, 0.0, 0.0};
   const int64_t n = B * D;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const float m = mu[i], lv = logvar[i];
-    const float kl = -0.5f * (1.f + lv - m * m - expf(lv));
-    s_raw += (double)kl;
-    s_floor += (double)((free_bits > 0.f) ? fmaxf(kl, free_bits) : kl);
+  for (int64_t i0 = threadIdx.x; i0 < n; i0 += 4096) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + 1024 * u;
+      if (i < n) {
+        const float m = mu[i], lv = logvar[i];
+        const float kl = -0.5f * (1.f + lv - m * m - expf(lv));
+        s_raw[u] += (double)kl;
+        s_floor[u] += (double)((free_bits > 0.f) ? fmaxf(kl, free_bits) : kl);
+      }
+    }
   }
-  s_floor = block_sum_256(s_floor, red);
-  s_raw = block_sum_256(s_raw, red);
+  const double a = wave_sum((s_floor[0] + s_floor[1]) + (s_floor[2] + s_floor[3]));
+  const double b = wave_sum((s_raw[0] + s_raw[1]) + (s_raw[2] + s_raw[3]));
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a;
+    red[1][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    out[0] = (float)(s_floor / (double)B);
-    out[1] = (float)(s_raw / (double)B);
-    out[2] = (float)(s_floor / (double)n);
+    double sf = 0.0, sr = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      sf += red[0][w];
+      sr += red[1][w];
+    }
+    out[0] = (float)(sf / (double)B);
+    out[1] = (float)(sr / (double)B);
+    out[2] = (float)(sf / (double)n);
   }
 }
 
@@ -344,7 +362,7 @@ __global__ void kl_bwd_kernel(const float* mu, const float* logvar, const float*
 extern "C" int dvae_kl_fwd_f32(const float* mu, const float* logvar, float* out, int64_t B, int64_t D,
                                float free_bits, dvae_stream_t stream) {
   DVAE_REQUIRE(B > 0 && D > 0, "kl_fwd: empty");
-  hipLaunchKernelGGL(kl_fwd_kernel, dim3(1), dim3(256), 0, ST(stream), mu, logvar, out, B, D, free_bits);
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3(1), dim3(1024), 0, ST(stream), mu, logvar, out, B, D, free_bits);
   DVAE_LAUNCH_CHECK("kl_fwd");
   return 0;
 }
