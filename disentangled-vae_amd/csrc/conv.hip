@@ -96,6 +96,7 @@ struct ConvArgs {
   const float* bn_shift;
   const float* bn_mean;
   const float* bn_invstd;
+  int round_bf16;   // row-ring kernels in bf16 mode: operands rounded to bf16 on their way into registers / LDS
 };
 
 // A operand of the forward implicit GEMMs.  MODE 0: conv (16 taps, input pixel 2*o-1+k);
@@ -531,7 +532,10 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int u = 0; u < NU; ++u)
-        wa[cb][t][u] = ldg4(g.wp + (((int64_t)phase * COUT + 16 * cb + i16) * 4 + t) * CIN + 16 * u + 4 * kq);
+      {
+        const f32x4 w = ldg4(g.wp + (((int64_t)phase * COUT + 16 * cb + i16) * 4 + t) * CIN + 16 * u + 4 * kq);
+        wa[cb][t][u] = g.round_bf16 ? round_bf16(w) : w;
+      }
   // loader role: this thread's pieces of a row are pieces threadIdx.x + 256 j; their channel offset is
   // the same for every j (C4 divides 256)
   const int lc4 = threadIdx.x % C4;
@@ -593,6 +597,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(z[e], zs[e]);
         }
+        if (g.round_bf16) v = round_bf16(v);
         *reinterpret_cast<f32x4*>(dst + (1 + f / C4) * PS + 4 * lc4) = v;
       }
     }
@@ -904,8 +909,8 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     DVAE_LAUNCH_CHECK(name);                                                                              \
     return 0;                                                                                             \
   }
-  // (in bf16 mode as well: at these sizes exact fp32 operands out of the row ring beat the tiled
-  // bf16 kernel)
+  // (in bf16 mode as well, with operands rounded to bf16 on the way in: at these sizes the row ring
+  // with the f32 MFMA beats the tiled bf16 kernel)
   ROWS_LAUNCH(32, 16, 2, 4)
   ROWS_LAUNCH(64, 32, 2, 2)
 #undef ROWS_LAUNCH
@@ -988,6 +993,7 @@ static int conv4s2_fwd_impl(const char* name, const float* x, const float* in_sc
   g.lc = is_pow2(Cin) ? ilog2(Cin) : -1;
   g.cin32 = Cin % 32 == 0;
   g.bn_y = bn.y; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_invstd = bn.invstd;
+  g.round_bf16 = 0;
   return launch_conv_fwd<0>(name, g, 1, stream);
 }
 
@@ -1008,6 +1014,7 @@ static int deconv4s2_fwd_impl(const char* name, const float* x, const float* in_
   g.lc = is_pow2(Cin) ? ilog2(Cin) : -1;
   g.cin32 = Cin % 32 == 0;
   g.bn_y = bn.y; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_invstd = bn.invstd;
+  g.round_bf16 = dvae_mfma_precision() == DVAE_PRECISION_BF16;
   return launch_conv_fwd<1>(name, g, 4, stream);
 }
 

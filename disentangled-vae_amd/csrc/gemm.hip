@@ -80,6 +80,101 @@ splitk_reduce_kernel(const float* __restrict__ slab, int split, const float* __r
   }
 }
 
+// Small products (a few hundred 16x16 output tiles, e.g. the latent heads at batch size): a tiled
+// launch would be a handful of workgroups walking K in 32-deep steps plus a split-K reduction.  Here a
+// workgroup owns one 16x16 tile, its eight waves split K between them and load their operand fragments
+// straight from memory into the register layout of v_mfma_f32_16x16x4_f32 (lane = row or column x
+// k quad; 16-byte loads along a k-contiguous operand, four 4-byte loads down a row-contiguous one),
+// all loads of a pass in flight together; the partial tiles meet in LDS, where bias, activation and
+// accumulation are applied.  One launch, no workspace.
+#define SG_WAVES 8
+#define SG_NF 4          // k groups of sixteen per wave and pass
+#define SG_RED_LD 17
+// BF: operands rounded to bf16 (the bf16 mode's contract), products still exact in the f32 MFMA.
+template <int KIND, bool BF>
+__global__ void __launch_bounds__(64 * SG_WAVES) small_gemm_kernel(GemmArgs g) {
+  __shared__ float red[SG_WAVES * 16 * SG_RED_LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int64_t n0 = (int64_t)blockIdx.x * 16, m0 = (int64_t)blockIdx.y * 16;
+  const bool rowok = m0 + i < g.M, colok = n0 + i < g.N;
+  const int64_t row = rowok ? m0 + i : g.M - 1, col = colok ? n0 + i : g.N - 1;
+  // the value to accumulate onto is requested first (threads 0..255 own one output each)
+  const int orow = (threadIdx.x >> 4) & 15, ocol = threadIdx.x & 15;
+  const bool owner = threadIdx.x < 256 && m0 + orow < g.M && n0 + ocol < g.N;
+  float* const op = g.C + (m0 + orow) * g.ldc + n0 + ocol;
+  float prev = 0.f, bias = 0.f;
+  if (owner && g.accumulate) prev = *op;
+  if (owner && g.bias) bias = g.bias[n0 + ocol];
+
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int64_t k0 = (int64_t)wave * 16 * SG_NF; k0 < g.K; k0 += 16 * SG_NF * SG_WAVES) {
+    f32x4 av[SG_NF], bv[SG_NF];
+#pragma unroll
+    for (int f = 0; f < SG_NF; ++f) {
+      const int64_t k = k0 + 16 * f + 4 * q;       // this lane's four k of group f
+      if (KIND != G_TN) {                          // A[m][k], k-contiguous (K % 4 == 0)
+        const bool ok = rowok && k < g.K;
+        const f32x4 v = ldg4(g.A + row * g.lda + (ok ? k : 0));
+        av[f] = zero_unless(v, ok);
+      } else {                                     // A[k][m]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = rowok && k + e < g.K;
+          const float v = g.A[(ok ? k + e : 0) * g.lda + row];
+          av[f][e] = ok ? v : 0.f;
+        }
+      }
+      if (KIND == G_NT) {                          // B[n][k], k-contiguous
+        const bool ok = colok && k < g.K;
+        const f32x4 v = ldg4(g.B + col * g.ldb + (ok ? k : 0));
+        bv[f] = zero_unless(v, ok);
+      } else {                                     // B[k][n]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = colok && k + e < g.K;
+          const float v = g.B[(ok ? k + e : 0) * g.ldb + col];
+          bv[f][e] = ok ? v : 0.f;
+        }
+      }
+    }
+    if (BF) {
+#pragma unroll
+      for (int f = 0; f < SG_NF; ++f) {
+        av[f] = round_bf16(av[f]);
+        bv[f] = round_bf16(bv[f]);
+      }
+    }
+    // two accumulators: consecutive MFMAs of a wave do not wait for each other's result
+#pragma unroll
+    for (int f = 0; f < SG_NF; ++f) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][0], bv[f][0], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][1], bv[f][1], acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][2], bv[f][2], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][3], bv[f][3], acc2, 0, 0, 0);
+    }
+  }
+  acc += acc2;
+  // D: row = 4q + r, column = i
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * q + r) * SG_RED_LD + i] = acc[r];
+  __syncthreads();
+  if (owner) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < SG_WAVES; ++w) s += red[(w * 16 + orow) * SG_RED_LD + ocol];
+    s += bias;
+    if (g.act == DVAE_ACT_LRELU) s = lrelu(s);
+    *op = s + prev;
+  }
+}
+
+// the small-product kernel pays when its tiles are few and the operand rows they re-read stay small
+static bool small_gemm_shape(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ceil_div64(M, 16) * ceil_div64(N, 16);
+  return tiles <= 1024 && tiles * K <= (1 << 20);
+}
+
 static int choose_split(int64_t tiles, int64_t ktiles) {
   int64_t s = 512 / (tiles > 0 ? tiles : 1);
   if (s > ktiles / 4) s = ktiles / 4;
@@ -108,12 +203,22 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K) {
 }
 
 extern "C" int64_t dvae_gemm_ws_floats(int64_t M, int64_t N, int64_t K) {
+  if (small_gemm_shape(M, N, K)) return 4;
   const Plan p = make_plan(M, N, K);
   return p.split > 1 ? (int64_t)p.split * M * N : 4;
 }
 
 template <int KIND>
 static int launch_gemm(const char* name, GemmArgs g, float* ws, hipStream_t stream) {
+  if (small_gemm_shape(g.M, g.N, g.K)) {
+    const dim3 grid((unsigned)ceil_div64(g.N, 16), (unsigned)ceil_div64(g.M, 16));
+    if (dvae_mfma_precision() == DVAE_PRECISION_BF16)
+      hipLaunchKernelGGL((small_gemm_kernel<KIND, true>), grid, dim3(64 * SG_WAVES), 0, stream, g);
+    else
+      hipLaunchKernelGGL((small_gemm_kernel<KIND, false>), grid, dim3(64 * SG_WAVES), 0, stream, g);
+    DVAE_LAUNCH_CHECK(name);
+    return 0;
+  }
   const Plan p = make_plan(g.M, g.N, g.K);
   g.ktiles_per_split = p.ktiles_per_split;
   g.slab = p.split > 1 ? ws : nullptr;

@@ -144,6 +144,15 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[T::TM][T::TN]) {
 }
 
 // ---- bf16-operand staging ------------------------------------------------------------------
+// the nearest bf16-representable values (round to nearest even), as floats
+__device__ __forceinline__ f32x4 round_bf16(f32x4 v) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  const bf16x2 a = __builtin_convertvector((f32x2_){v[0], v[1]}, bf16x2);
+  const bf16x2 b = __builtin_convertvector((f32x2_){v[2], v[3]}, bf16x2);
+  const f32x2_ fa = __builtin_convertvector(a, f32x2_), fb = __builtin_convertvector(b, f32x2_);
+  return (f32x4){fa[0], fa[1], fb[0], fb[1]};
+}
+
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
   const f32x2 v = {lo, hi};
   const bf16x2 b = __builtin_convertvector(v, bf16x2);   // v_cvt_pk_bf16_f32, round to nearest even
