@@ -102,8 +102,14 @@ class KernelTimer:
         setattr(self.ops, name, wrapped)
 
     def install(self):
-        def tile(c):
-            return 'T128' if c > 64 else ('T64' if c > 32 else 'T32')
+        def tile(c, rows=None, phases=1):
+            """tile the launcher picks: by output channels, narrowed while fewer than 256 workgroups"""
+            bn = 128 if c > 64 else (64 if c > 32 else 32)
+            if rows is not None:
+                row_tiles = -(-rows // 128) * phases
+                while bn > 32 and row_tiles * -(-c // bn) < 256:
+                    bn //= 2
+            return f'T{bn}'
 
         def conv_key(x, sc, sh, act, wp, stats):
             N, H, W, Cin = x.shape
@@ -113,7 +119,7 @@ class KernelTimer:
             fl = 2.0 * N * (H // 2) * (W // 2) * Cout * 16 * Cin
             if (Cin, Cout) in ((32, 64), (16, 32)) and 32 <= W <= 64:     # few channels: rows through an LDS ring
                 return f"conv_rows_kernel<{Cin},{Cout}>", fl, 'flop'
-            return f"conv_fwd_kernel<{tile(Cout)},conv>", fl, 'flop'
+            return f"conv_fwd_kernel<{tile(Cout, N * (H // 2) * (W // 2))},conv>", fl, 'flop'
 
         def conv_bn_key(x, wp, bn_y, aff):
             key, work, unit = conv_key(x, None, None, 0, wp, True)
@@ -131,7 +137,7 @@ class KernelTimer:
             fl = 2.0 * N * 4 * H * W * Cout * 4 * Cin
             if (Cin, Cout) in ((32, 16), (64, 32)) and 16 <= W <= 32:   # few channels: rows through an LDS ring
                 return f"deconv_rows_kernel<{Cin},{Cout}>", fl, 'flop'
-            return f"conv_fwd_kernel<{tile(Cout)},deconv>", fl, 'flop'
+            return f"conv_fwd_kernel<{tile(Cout, N * H * W, 4)},deconv>", fl, 'flop'
 
         def wgrad_key(P, ps, ph, pa, Q, qs, qh, qa):
             N, Hs, Ws, C1 = P.shape

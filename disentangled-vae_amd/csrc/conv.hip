@@ -952,12 +952,18 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
 #undef C1_LAUNCH
   } else if (c1) {
     if (g.Cout > 32) LAUNCH(T64, true) else LAUNCH(T32, true)
-  } else if (g.Cout > 64) {
-    LAUNCH(T128, false)
-  } else if (g.Cout > 32) {
-    LAUNCH(T64, false)
   } else {
-    LAUNCH(T32, false)
+    // the widest tile that still gives every compute unit a workgroup (all tiles are 128 rows high)
+    const int64_t row_tiles = ceil_div64(g.M, 128) * phases;
+    int bn = g.Cout > 64 ? 128 : (g.Cout > 32 ? 64 : 32);
+    while (bn > 32 && row_tiles * ceil_div64(g.Cout, bn) < 256) bn >>= 1;
+    if (bn == 128) {
+      LAUNCH(T128, false)
+    } else if (bn == 64) {
+      LAUNCH(T64, false)
+    } else {
+      LAUNCH(T32, false)
+    }
   }
 #undef LAUNCH
   DVAE_LAUNCH_CHECK(name);

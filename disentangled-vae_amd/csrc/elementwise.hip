@@ -721,19 +721,25 @@ colsum_finalize_kernel(const float* __restrict__ partials, int64_t nparts, int N
   }
 }
 
+// dx = scale * (dz - dbeta/M - xhat * dgamma/M), dz = du * lrelu'(scale*y + shift), in place over du.
+// The launch makes the grid stride a multiple of C/4, so a thread meets the same four channels in
+// every iteration and keeps their six constants in registers.
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(float4* __restrict__ du, const float4* __restrict__ y, const float* __restrict__ scale,
                     const float* __restrict__ shift, const float* __restrict__ mean,
                     const float* __restrict__ invstd, const float* __restrict__ dbeta,
                     const float* __restrict__ dgamma, float invM, int64_t total4, int C4) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % C4) * 4;
-    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
-    const float4 sh = *reinterpret_cast<const float4*>(shift + c);
-    const float4 mu = *reinterpret_cast<const float4*>(mean + c);
-    const float4 is = *reinterpret_cast<const float4*>(invstd + c);
-    const float4 db = *reinterpret_cast<const float4*>(dbeta + c);
-    const float4 dg = *reinterpret_cast<const float4*>(dgamma + c);
+  const int64_t first = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  const int c = (int)(first % C4) * 4;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+  const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+  const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+  const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+  float4 k1 = *reinterpret_cast<const float4*>(dbeta + c);      // dbeta/M
+  float4 k2 = *reinterpret_cast<const float4*>(dgamma + c);     // dgamma/M
+  k1.x *= invM; k1.y *= invM; k1.z *= invM; k1.w *= invM;
+  k2.x *= invM; k2.y *= invM; k2.z *= invM; k2.w *= invM;
+  for (int64_t i = first; i < total4; i += stride) {
     const float4 g = du[i];
     const float4 yv = y[i];
     float4 o;
@@ -742,12 +748,27 @@ bn_bwd_apply_kernel(float4* __restrict__ du, const float4* __restrict__ y, const
     const float z = fmaf(yv.f, sc.f, sh.f);                               \
     const float dz = z > 0.f ? g.f : g.f * LRELU_SLOPE;                   \
     const float xh = (yv.f - mu.f) * is.f;                                \
-    o.f = sc.f * (dz - db.f * invM - xh * (dg.f * invM));                 \
+    o.f = sc.f * (dz - k1.f - xh * k2.f);                                 \
   }
     BN_ONE(x) BN_ONE(y) BN_ONE(z) BN_ONE(w)
 #undef BN_ONE
     du[i] = o;
   }
+}
+
+// grid of the apply kernel: at most 4096 workgroups, and 256 * gridDim.x a multiple of C/4
+static unsigned bn_apply_blocks(int64_t total4, int64_t C4) {
+  int64_t nb = ceil_div64(total4, 256);
+  if (nb > 4096) nb = 4096;
+  int64_t unit = C4;                     // smallest nb with (256 nb) % C4 == 0 is C4 / gcd(256, C4)
+  for (int64_t a = 256, b = C4; b != 0;) {
+    const int64_t t = a % b;
+    a = b;
+    b = t;
+    unit = C4 / a;
+  }
+  nb = ceil_div64(nb, unit) * unit;
+  return (unsigned)nb;
 }
 
 extern "C" int dvae_bn_bwd_f32(float* du, const float* y, const float* scale, const float* shift, const float* mean,
@@ -763,9 +784,7 @@ extern "C" int dvae_bn_bwd_f32(float* du, const float* y, const float* scale, co
                      dbeta, dgamma);
   DVAE_LAUNCH_CHECK("bn_bwd_finalize");
   const int64_t total4 = M * C / 4;
-  int64_t nb = ceil_div64(total4, 256);
-  if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), (float4*)du, (const float4*)y,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_blocks(total4, C / 4)), dim3(256), 0, ST(stream), (float4*)du, (const float4*)y,
                      scale, shift, mean, invstd, (const float*)dbeta, (const float*)dgamma, 1.f / (float)M, total4,
                      (int)(C / 4));
   DVAE_LAUNCH_CHECK("bn_bwd_apply");
@@ -782,9 +801,7 @@ extern "C" int dvae_bn_bwd_from_partials_f32(float* du, const float* y, const fl
                      dgamma);
   DVAE_LAUNCH_CHECK("bn_bwd_finalize");
   const int64_t total4 = M * C / 4;
-  int64_t nb = ceil_div64(total4, 256);
-  if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), (float4*)du, (const float4*)y,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_blocks(total4, C / 4)), dim3(256), 0, ST(stream), (float4*)du, (const float4*)y,
                      scale, shift, mean, invstd, (const float*)dbeta, (const float*)dgamma, 1.f / (float)M, total4,
                      (int)(C / 4));
   DVAE_LAUNCH_CHECK("bn_bwd_apply");
