@@ -127,6 +127,10 @@ class KernelTimer:
                 return key + ',bnstat', work + float(bn_y.numel() * 4), unit
             return key[:-1] + ',bnstat>', work, unit
 
+        def conv_bnin_key(du_in, in_y, in_aff, ca, cb, wp, bn_y, bn_aff):
+            key, work, unit = conv_key(du_in, None, None, 0, wp, True)
+            return key[:-1] + ',bnstat,bnin>', work, unit
+
         def deconv_bn_key(x, wp, bn_y, aff):
             key, work, unit = deconv_key(x, None, None, 0, wp, True)
             return key[:-1] + ',bnstat>', work, unit
@@ -197,6 +201,7 @@ class KernelTimer:
         self._wrap('deconv4s2_fwd', deconv_key)
         self._wrap('conv4s2_dgrad_bnstat', conv_bn_key)
         self._wrap('deconv4s2_dgrad_bnstat', deconv_bn_key)
+        self._wrap('conv4s2_dgrad_bnstat_bnin', conv_bnin_key)
         self._wrap('conv4s2_wgrad', wgrad_key)
         self._wrap('gemm_nt', gemm_key('nt'))
         self._wrap('gemm_nn', gemm_key('nn'))

@@ -96,6 +96,12 @@ struct ConvArgs {
   const float* bn_shift;
   const float* bn_mean;
   const float* bn_invstd;
+  // input not yet through its BatchNorm backward (conv_rows_kernel, BNIN): raw output of that layer,
+  // the two folded coefficient vectors, and where the finished gradient rows go
+  const float* in_y;
+  const float* in_a;
+  const float* in_b;
+  float* dx_out;
   int round_bf16;   // row-ring kernels in bf16 mode: operands rounded to bf16 on their way into registers / LDS
 };
 
@@ -696,12 +702,20 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
 // from LDS.  A row slot holds the even and the odd input columns apart, so that the sixteen lanes of a
 // read (output pixels ob..ob+15, input column 2ob-1+kw) touch consecutive pixels: the odd columns are
 // preceded by a zero pixel (column -1) and the even ones followed by one (column W).
-template <int CIN, int COUT, int WAVES_PER_EU, bool XF, bool BNS>
+//
+// BNIN: the input is the gradient of a BatchNorm + LeakyReLU layer's activation that has not been
+// taken through the BatchNorm backward yet.  x is du, in_y the layer's raw output, and a row becomes
+// dx = scale * dz + A * y + B (dz = du * lrelu'(scale * y + shift); A, B fold the batch sums, see
+// dvae_bn_bwd_coeffs_f32) on its way into LDS -- the elementwise BatchNorm-backward pass over the
+// tensor disappears.  The rows a workgroup owns (not its halo rows) are also written to dx_out for
+// the weight-gradient kernel.
+template <int CIN, int COUT, int WAVES_PER_EU, bool XF, bool BNS, bool BNIN>
 __global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvArgs g) {
   constexpr int NU = CIN / 16, NT = COUT * 4;
   constexpr int PS = CIN + 4;                       // pixel stride in LDS: 16-byte reads without bank conflicts
   constexpr int C4 = CIN / 4;                       // 16-byte pieces per pixel
-  constexpr int NLD = (64 * C4 + NT - 1) / NT;      // 16-byte pieces of a row per thread, at most (W <= 64)
+  constexpr int WMAX = BNIN ? 32 : 64;              // widest frame (the BNIN variant holds two tensors' rows)
+  constexpr int NLD = (WMAX * C4 + NT - 1) / NT;    // 16-byte pieces of a row per thread, at most
   extern __shared__ __attribute__((aligned(16))) float ring[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, kq = lane >> 4;
@@ -718,9 +732,14 @@ __global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvA
   const int lc4 = threadIdx.x % C4;
   f32x4 sc = (f32x4){1.f, 1.f, 1.f, 1.f}, sh = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float slope = g.in_act == DVAE_ACT_LRELU ? LRELU_SLOPE : 1.f;
-  if (XF && g.in_scale) {
+  if ((XF || BNIN) && g.in_scale) {
     sc = ldg4(g.in_scale + 4 * lc4);
     sh = ldg4(g.in_shift + 4 * lc4);
+  }
+  f32x4 ca = sh, cb = sh;
+  if (BNIN) {
+    ca = ldg4(g.in_a + 4 * lc4);
+    cb = ldg4(g.in_b + 4 * lc4);
   }
   const int row_pieces = W * C4;
   f32x4 bsc, bsh, bmu, bis;
@@ -746,23 +765,38 @@ __global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvA
   const int64_t r0 = (int)blockIdx.x < g.mtiles ? blockIdx.x * per : rows;
   const int64_t r1 = r0 + per < rows ? r0 + per : rows;
 
-  auto fetch = [&](int64_t row, f32x4 (&raw)[NLD]) {      // issue the loads of an input row (if it exists)
+  struct Raw {
+    f32x4 v[NLD], y[BNIN ? NLD : 1];
+  };
+  auto fetch = [&](int64_t row, Raw& raw) {      // issue the loads of an input row (if it exists)
     const bool rok = row >= 0 && row < rows_in;
-    const float* src = g.x + (rok ? row : 0) * (int64_t)row_pieces * 4;
+    const int64_t off = (rok ? row : 0) * (int64_t)row_pieces * 4;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int f = threadIdx.x + NT * j;
-      raw[j] = ldg4(src + 4 * (rok && f < row_pieces ? f : 0));
+      const int64_t o = off + 4 * (rok && f < row_pieces ? f : 0);
+      raw.v[j] = ldg4(g.x + o);
+      if (BNIN) raw.y[j] = ldg4(g.in_y + o);
     }
   };
-  auto deposit = [&](int64_t row, const f32x4 (&raw)[NLD]) {   // transform, split by column parity, store
+  auto deposit = [&](int64_t row, const Raw& raw) {   // transform, split by column parity, store
     float* dst = ring + (row & 7) * slot_floats;
+    const bool owned = BNIN && row >= 2 * r0 && row < 2 * r1;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int f = threadIdx.x + NT * j;
       if (f < row_pieces) {
-        f32x4 v = raw[j];
-        if (XF) {
+        f32x4 v = raw.v[j];
+        if (BNIN) {
+          const f32x4 y = raw.y[j];
+          const f32x4 z = y * sc + sh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dz = z[e] > 0.f ? v[e] : v[e] * LRELU_SLOPE;
+            v[e] = fmaf(sc[e], dz, fmaf(ca[e], y[e], cb[e]));
+          }
+          if (owned) *reinterpret_cast<f32x4*>(g.dx_out + row * (int64_t)row_pieces * 4 + 4 * f) = v;
+        } else if (XF) {
           const f32x4 z = v * sc + sh;       // slope <= 1: lrelu(z) = max(z, slope z)
           const f32x4 zs = z * slope;
 #pragma unroll
@@ -774,7 +808,7 @@ __global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvA
       }
     }
   };
-  f32x4 rawa[NLD], rawb[NLD];
+  Raw rawa, rawb;
   if (r0 < r1) {
     fetch(2 * r0 - 1, rawa);
     fetch(2 * r0, rawb);
@@ -922,20 +956,29 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     g.mtiles = (int)grid.x < 256 * RESIDENT ? (int)grid.x : 256 * RESIDENT;                               \
     const size_t lds = (size_t)8 * 2 * (g.W / 2 + 1) * (CI + 4) * sizeof(float);                          \
     const bool xf = g.in_scale != nullptr || g.in_act != DVAE_ACT_NONE;                                   \
-    if (bns && xf)                                                                                        \
-      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, true, true>), grid, dim3(CO * 4), lds, stream, g); \
+    if (g.in_y != nullptr && bns)                                                                         \
+      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, false, true, true>), grid, dim3(CO * 4), lds, stream, g); \
+    else if (g.in_y != nullptr) {                                                                         \
+      dvae_set_error("%s: a BatchNorm-backward input needs the fused statistics of the layer below", name); \
+      return -EINVAL;                                                                                     \
+    } else if (bns && xf)                                                                                 \
+      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, true, true, false>), grid, dim3(CO * 4), lds, stream, g); \
     else if (bns)                                                                                         \
-      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, false, true>), grid, dim3(CO * 4), lds, stream, g); \
+      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, false, true, false>), grid, dim3(CO * 4), lds, stream, g); \
     else if (xf)                                                                                          \
-      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, true, false>), grid, dim3(CO * 4), lds, stream, g); \
+      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, true, false, false>), grid, dim3(CO * 4), lds, stream, g); \
     else                                                                                                  \
-      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, false, false>), grid, dim3(CO * 4), lds, stream, g); \
+      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, false, false, false>), grid, dim3(CO * 4), lds, stream, g); \
     DVAE_LAUNCH_CHECK(name);                                                                              \
     return 0;                                                                                             \
   }
   CONV_ROWS_LAUNCH(32, 64, 2, 2)
   CONV_ROWS_LAUNCH(16, 32, 2, 4)
 #undef CONV_ROWS_LAUNCH
+  if (g.in_y != nullptr) {
+    dvae_set_error("%s: no kernel takes a BatchNorm-backward input at this shape (see dvae_conv4s2_bnin_supported)", name);
+    return -EINVAL;
+  }
   if (c1 && MODE == 0 && g.Cout <= 64 && aligned16(g.y) && (!bns || aligned16(g.bn_y))) {
     // one partial-statistics row per workgroup, as many rows as the caller sized the buffer for
     const dim3 grid((unsigned)conv_parts_written(g.M, 1));
@@ -977,10 +1020,17 @@ struct BnBwdStat {   // see ConvArgs::bn_y
   const float* mean;
   const float* invstd;
 };
+struct BnBwdInput {  // see ConvArgs::in_y
+  const float* y;
+  const float* a;
+  const float* b;
+  float* dx_out;
+};
 
 static int conv4s2_fwd_impl(const char* name, const float* x, const float* in_scale, const float* in_shift, int in_act,
                             const float* wp, float* y, float* stat_partials, int64_t N, int64_t H, int64_t W,
-                            int64_t Cin, int64_t Cout, const BnBwdStat& bn, hipStream_t stream) {
+                            int64_t Cin, int64_t Cout, const BnBwdStat& bn, hipStream_t stream,
+                            const BnBwdInput& bi = BnBwdInput{nullptr, nullptr, nullptr, nullptr}) {
   DVAE_REQUIRE(N > 0 && Cout > 0, "%s: empty", name);
   DVAE_REQUIRE(is_pow2(H) && is_pow2(W) && H >= 2 && W >= 2, "%s: H and W must be powers of two >= 2 (H=%ld W=%ld)", name,
                (long)H, (long)W);
@@ -1000,6 +1050,10 @@ static int conv4s2_fwd_impl(const char* name, const float* x, const float* in_sc
   g.cin32 = Cin % 32 == 0;
   g.bn_y = bn.y; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_invstd = bn.invstd;
   g.round_bf16 = 0;
+  g.in_y = bi.y; g.in_a = bi.a; g.in_b = bi.b; g.dx_out = bi.dx_out;
+  DVAE_REQUIRE(bi.y == nullptr || (in_scale && in_shift && bi.a && bi.b && bi.dx_out && aligned16(bi.y) &&
+                                   aligned16(bi.a) && aligned16(bi.b) && aligned16(bi.dx_out)),
+               "%s: a BatchNorm-backward input needs y, scale, shift, A, B and dx_out, 16-byte aligned", name);
   return launch_conv_fwd<0>(name, g, 1, stream);
 }
 
@@ -1021,6 +1075,7 @@ static int deconv4s2_fwd_impl(const char* name, const float* x, const float* in_
   g.cin32 = Cin % 32 == 0;
   g.bn_y = bn.y; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_invstd = bn.invstd;
   g.round_bf16 = dvae_mfma_precision() == DVAE_PRECISION_BF16;
+  g.in_y = nullptr; g.in_a = nullptr; g.in_b = nullptr; g.dx_out = nullptr;
   return launch_conv_fwd<1>(name, g, 4, stream);
 }
 
@@ -1045,6 +1100,24 @@ extern "C" int dvae_conv4s2_dgrad_bnstat_f32(const float* x, const float* wp, fl
   DVAE_REQUIRE(bn_y != nullptr, "conv4s2_dgrad_bnstat: bn_y is null");
   return conv4s2_fwd_impl("conv4s2_dgrad_bnstat", x, nullptr, nullptr, DVAE_ACT_NONE, wp, y, stat_partials, N, H, W,
                           Cin, Cout, BnBwdStat{bn_y, bn_scale, bn_shift, bn_mean, bn_invstd}, ST(stream));
+}
+
+extern "C" int dvae_conv4s2_bnin_supported(int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
+  (void)H;
+  return dvae_mfma_precision() == DVAE_PRECISION_F32 && Cin == 32 && Cout == 64 && W == 32;
+}
+
+extern "C" int dvae_conv4s2_dgrad_bnstat_bnin_f32(const float* du_in, const float* in_y, const float* in_scale,
+                                                  const float* in_shift, const float* in_a, const float* in_b,
+                                                  float* dx_out, const float* wp, float* y, float* stat_partials,
+                                                  int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                                                  const float* bn_y, const float* bn_scale, const float* bn_shift,
+                                                  const float* bn_mean, const float* bn_invstd, dvae_stream_t stream) {
+  DVAE_REQUIRE(bn_y != nullptr && in_y != nullptr, "conv4s2_dgrad_bnstat_bnin: bn_y / in_y is null");
+  DVAE_REQUIRE(dvae_conv4s2_bnin_supported(H, W, Cin, Cout), "conv4s2_dgrad_bnstat_bnin: unsupported shape or precision");
+  return conv4s2_fwd_impl("conv4s2_dgrad_bnstat_bnin", du_in, in_scale, in_shift, DVAE_ACT_NONE, wp, y, stat_partials, N,
+                          H, W, Cin, Cout, BnBwdStat{bn_y, bn_scale, bn_shift, bn_mean, bn_invstd}, ST(stream),
+                          BnBwdInput{in_y, in_a, in_b, dx_out});
 }
 
 extern "C" int dvae_deconv4s2_dgrad_bnstat_f32(const float* x, const float* wp, float* y, float* stat_partials,

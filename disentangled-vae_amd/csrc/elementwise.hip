@@ -721,6 +721,44 @@ colsum_finalize_kernel(const float* __restrict__ partials, int64_t nparts, int N
   }
 }
 
+// Batch sums of a BatchNorm backward and the two vectors that fold them into the elementwise step:
+// dx = scale * (dz - dbeta/M - xhat * dgamma/M) = scale * dz + A * y + B with
+// A = -scale * invstd * dgamma / M and B = -scale * dbeta / M - A * mean.
+__global__ void __launch_bounds__(256)
+bn_bwd_coeffs_kernel(const float* __restrict__ partials, int64_t nparts, int64_t C, const float* __restrict__ scale,
+                     const float* __restrict__ mean, const float* __restrict__ invstd, float invM,
+                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef_a,
+                     float* __restrict__ coef_b) {
+  __shared__ double red[4];
+  const int64_t c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t p = threadIdx.x; p < nparts; p += 256) {
+    s1 += (double)partials[(p * 2 + 0) * C + c];
+    s2 += (double)partials[(p * 2 + 1) * C + c];
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  if (threadIdx.x == 0) {
+    const float db = (float)s1, dg = (float)s2;
+    dbeta[c] = db;
+    dgamma[c] = dg;
+    const float a = -scale[c] * invstd[c] * (dg * invM);
+    coef_a[c] = a;
+    coef_b[c] = -scale[c] * (db * invM) - a * mean[c];
+  }
+}
+
+extern "C" int dvae_bn_bwd_coeffs_f32(const float* partials, int64_t nparts, const float* scale, const float* mean,
+                                      const float* invstd, float* dgamma, float* dbeta, float* coef_a, float* coef_b,
+                                      int64_t M, int64_t C, dvae_stream_t stream) {
+  DVAE_REQUIRE(M > 0 && C > 0 && nparts > 0, "bn_bwd_coeffs: empty");
+  DVAE_REQUIRE(partials && scale && mean && invstd && dgamma && dbeta && coef_a && coef_b, "bn_bwd_coeffs: null argument");
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), partials, nparts, C, scale, mean,
+                     invstd, 1.f / (float)M, dgamma, dbeta, coef_a, coef_b);
+  DVAE_LAUNCH_CHECK("bn_bwd_coeffs");
+  return 0;
+}
+
 // dx = scale * (dz - dbeta/M - xhat * dgamma/M), dz = du * lrelu'(scale*y + shift), in place over du.
 // The launch makes the grid stride a multiple of C/4, so a thread meets the same four channels in
 // every iteration and keeps their six constants in registers.

@@ -203,14 +203,22 @@ class DecoderCNN(torch.autograd.Function):
         d_dec, d_gamma, d_beta = [None] * L, [None] * L, [None] * L
         for l in range(L - 1, -1, -1):
             sc, sh, mean, invstd = affs[l]
-            d_gamma[l], d_beta[l] = ops.bn_bwd(du, ys[l], sc, sh, mean, invstd, ctx.gammas[l], parts)
-            dy = du
+            wp = ops.pack_conv_w(dec_w[l])        # [Cin_d][4][4][Cout_d]: the adjoint is a plain conv
             if l > 0:
                 pin, psc, psh, pact = ys[l - 1], affs[l - 1][0], affs[l - 1][1], ops.ACT_LRELU
             else:
                 pin, psc, psh, pact = h0.view(N, 4, 4, C0), None, None, ops.ACT_NONE
+            if (parts is not None and l > 0 and _fuse_bn_stats(ys[l - 1].shape[-1])
+                    and ops.conv4s2_bnin_supported(du, wp.shape[0])):
+                # the data-gradient kernel takes du through this layer's BatchNorm backward as it loads
+                # it and hands the finished dL/dy to the weight gradient: no elementwise pass
+                d_gamma[l], d_beta[l], ca, cb = ops.bn_bwd_coeffs(parts, affs[l], du.numel() // du.shape[-1])
+                du, parts, dy = ops.conv4s2_dgrad_bnstat_bnin(du, ys[l], affs[l], ca, cb, wp, ys[l - 1], affs[l - 1])
+                d_dec[l] = ops.conv4s2_wgrad(pin, psc, psh, pact, dy, None, None, ops.ACT_NONE)
+                continue
+            d_gamma[l], d_beta[l] = ops.bn_bwd(du, ys[l], sc, sh, mean, invstd, ctx.gammas[l], parts)
+            dy = du
             d_dec[l] = ops.conv4s2_wgrad(pin, psc, psh, pact, dy, None, None, ops.ACT_NONE)
-            wp = ops.pack_conv_w(dec_w[l])        # [Cin_d][4][4][Cout_d]: the adjoint is a plain conv
             if l > 0 and _fuse_bn_stats(ys[l - 1].shape[-1]):
                 du, parts = ops.conv4s2_dgrad_bnstat(dy, wp, ys[l - 1], affs[l - 1])
             else:

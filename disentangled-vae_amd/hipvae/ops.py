@@ -382,6 +382,45 @@ def conv4s2_dgrad_bnstat(x: Tensor, wp: Tensor, bn_y: Tensor, bn_aff):
     return y, stats
 
 
+def bn_bwd_coeffs(partials: Tensor, aff, M: int):
+    """From the partial rows of a *_dgrad_bnstat call and the layer's (scale, shift, mean, invstd):
+    (dgamma, dbeta, A, B) with dL/dy = scale*dz + A*y + B."""
+    sc, sh, mean, invstd = aff
+    _chk(partials, sc, mean, invstd)
+    C = sc.shape[0]
+    out = torch.empty(4, C, dtype=torch.float32, device=sc.device)
+    check(lib.dvae_bn_bwd_coeffs_f32(_p(partials), partials.shape[0], _p(sc), _p(mean), _p(invstd), _p(out[0]),
+                                     _p(out[1]), _p(out[2]), _p(out[3]), M, C, _stream()), 'bn_bwd_coeffs')
+    return out[0], out[1], out[2], out[3]
+
+
+def conv4s2_bnin_supported(x: Tensor, Cout: int) -> bool:
+    N, H, W, Cin = x.shape
+    return bool(lib.dvae_conv4s2_bnin_supported(H, W, Cin, Cout))
+
+
+def conv4s2_dgrad_bnstat_bnin(du_in: Tensor, in_y: Tensor, in_aff, coef_a: Tensor, coef_b: Tensor, wp: Tensor,
+                              bn_y: Tensor, bn_aff):
+    """conv4s2_dgrad_bnstat on an input that still needs its own BatchNorm backward: du_in is the gradient
+    of the activation of the layer whose raw output is in_y; returns (du, partials, dx) where dx is the
+    finished dL/d(in_y) (for the weight-gradient call)."""
+    _chk(du_in, in_y, wp, bn_y, coef_a, coef_b, *in_aff, *bn_aff)
+    assert du_in.shape == in_y.shape
+    N, H, W, Cin = du_in.shape
+    Cout = wp.shape[0]
+    y = torch.empty(N, H // 2, W // 2, Cout, dtype=torch.float32, device=du_in.device)
+    assert bn_y.shape == y.shape
+    dx = torch.empty_like(du_in)
+    nparts = lib.dvae_conv_stat_parts_written(N * (H // 2) * (W // 2), 1)
+    stats = torch.empty(nparts, 2, Cout, dtype=torch.float32, device=du_in.device)
+    sc, sh, mean, invstd = bn_aff
+    check(lib.dvae_conv4s2_dgrad_bnstat_bnin_f32(_p(du_in), _p(in_y), _p(in_aff[0]), _p(in_aff[1]), _p(coef_a),
+                                                 _p(coef_b), _p(dx), _p(wp), _p(y), _p(stats), N, H, W, Cin, Cout,
+                                                 _p(bn_y), _p(sc), _p(sh), _p(mean), _p(invstd), _stream()),
+          'conv4s2_dgrad_bnstat_bnin')
+    return y, stats, dx
+
+
 def deconv4s2_dgrad_bnstat(x: Tensor, wp: Tensor, bn_y: Tensor, bn_aff):
     """deconv4s2_fwd used as a data gradient, with the same fused statistics (see conv4s2_dgrad_bnstat)."""
     _chk(x, wp, bn_y, *bn_aff)

@@ -123,6 +123,12 @@ int dvae_bn_bwd_f32(float* du, const float* y, const float* scale, const float* 
                     int64_t M, int64_t C, dvae_stream_t stream);
 /* The same with step 1 done elsewhere: partials[nparts][2][C] rows of (sum dz, sum dz*xhat) as written by
  * dvae_conv4s2_dgrad_bnstat_f32 / dvae_deconv4s2_dgrad_bnstat_f32 while they produced du. */
+/* Step 1's finish alone, for consumers that apply step 2 themselves as they load du (see
+ * dvae_conv4s2_dgrad_bnstat_bnin_f32): dgamma, dbeta from the partial rows, and the vectors A, B with
+ * dL/dy = scale*dz + A*y + B  (A = -scale*invstd*dgamma/M, B = -scale*dbeta/M - A*mean). */
+int dvae_bn_bwd_coeffs_f32(const float* partials, int64_t nparts, const float* scale, const float* mean,
+                           const float* invstd, float* dgamma, float* dbeta, float* coef_a, float* coef_b,
+                           int64_t M, int64_t C, dvae_stream_t stream);
 int dvae_bn_bwd_from_partials_f32(float* du, const float* y, const float* scale, const float* shift,
                                   const float* mean, const float* invstd, const float* partials, int64_t nparts,
                                   float* dgamma, float* dbeta, int64_t M, int64_t C, dvae_stream_t stream);
@@ -195,6 +201,21 @@ int dvae_conv4s2_dgrad_bnstat_f32(const float* x, const float* wp, float* y, flo
                                   int64_t H, int64_t W, int64_t Cin, int64_t Cout, const float* bn_y,
                                   const float* bn_scale, const float* bn_shift, const float* bn_mean,
                                   const float* bn_invstd, dvae_stream_t stream);
+/* dvae_conv4s2_dgrad_bnstat_f32 whose input has not been through its own BatchNorm backward yet (the
+ * decoder's conv-transpose -> BatchNorm -> LeakyReLU blocks, models/decoders.py:40-45, walked backwards):
+ * du_in is dL/d(activation) of the layer above, in_y that layer's raw output, in_scale/in_shift its
+ * folded forward statistics and in_a/in_b the vectors of dvae_bn_bwd_coeffs_f32.  The kernel forms
+ * dL/d(in_y) row by row as it loads, uses it as the convolution input and also writes it to dx_out
+ * (shaped like du_in) for the weight-gradient call; the separate elementwise pass of
+ * dvae_bn_bwd_from_partials_f32 is not needed.  Only where dvae_conv4s2_bnin_supported says so
+ * (few-channel layers in fp32 mode); otherwise -EINVAL. */
+int dvae_conv4s2_bnin_supported(int64_t H, int64_t W, int64_t Cin, int64_t Cout);
+int dvae_conv4s2_dgrad_bnstat_bnin_f32(const float* du_in, const float* in_y, const float* in_scale,
+                                       const float* in_shift, const float* in_a, const float* in_b,
+                                       float* dx_out, const float* wp, float* y, float* stat_partials,
+                                       int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                                       const float* bn_y, const float* bn_scale, const float* bn_shift,
+                                       const float* bn_mean, const float* bn_invstd, dvae_stream_t stream);
 int dvae_deconv4s2_dgrad_bnstat_f32(const float* x, const float* wp, float* y, float* stat_partials, int64_t N,
                                     int64_t H, int64_t W, int64_t Cin, int64_t Cout, const float* bn_y,
                                     const float* bn_scale, const float* bn_shift, const float* bn_mean,

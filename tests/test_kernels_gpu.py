@@ -495,6 +495,48 @@ def test_device_rendered_batches_are_bit_identical(ops, kwargs, seed):
             assert all(np.array_equal(x, y) for x, y in zip(a['initial_velocities'], b['initial_velocities']))
 
 
+# ------------------------------------------------------------------ BatchNorm backward folded into the consumer's loads
+@pytest.mark.parametrize('N,H', [(3, 32), (70, 32)])
+def test_dgrad_that_applies_the_bn_backward_of_its_input(ops, N, H):
+    """conv4s2_dgrad_bnstat_bnin against the three-step path it replaces (bn_bwd from partials, then
+    conv4s2_dgrad_bnstat): same dgamma/dbeta, the finished dL/dy it hands on, its own output and the
+    statistics of the layer below."""
+    Cin, Cout = 32, 64
+    du = rnd(N, H, H, Cin, seed=90)                    # NHWC throughout
+    y = rnd(N, H, H, Cin, seed=91)
+    gamma, beta = 1 + 0.3 * rnd(Cin, seed=92), 0.2 * rnd(Cin, seed=93)
+    mean, var = y.mean(dim=(0, 1, 2)), y.var(dim=(0, 1, 2), unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    sc, sh = gamma * invstd, beta - mean * gamma * invstd
+    aff = (dev(sc), dev(sh), dev(mean), dev(invstd))
+    z = y * sc + sh
+    dz = du * torch.where(z > 0, 1.0, 0.2)
+    xhat = (y - mean) * invstd
+    M = N * H * H
+    # partial rows as a producer would leave them (any split of the sums will do)
+    parts = torch.stack([torch.stack([dz.sum(dim=(0, 1, 2)) * f, (dz * xhat).sum(dim=(0, 1, 2)) * f])
+                         for f in (0.25, 0.75)])
+    w = rnd(Cout, Cin, 4, 4, seed=94, scale=0.2)
+    wp = ops.pack_conv_w(dev(w))
+    y_below = rnd(N, H // 2, H // 2, Cout, seed=95)
+    gb, bb = 1 + 0.3 * rnd(Cout, seed=96), 0.2 * rnd(Cout, seed=97)
+    mb, vb = y_below.mean(dim=(0, 1, 2)), y_below.var(dim=(0, 1, 2), unbiased=False)
+    ib = 1 / torch.sqrt(vb + 1e-5)
+    aff_below = (dev(gb * ib), dev(bb - mb * gb * ib), dev(mb), dev(ib))
+    assert ops.conv4s2_bnin_supported(dev(du), Cout)
+    dg, db, ca, cb = ops.bn_bwd_coeffs(dev(parts), aff, M)
+    got_du, got_parts, got_dx = ops.conv4s2_dgrad_bnstat_bnin(dev(du), dev(y), aff, ca, cb, wp, dev(y_below), aff_below)
+    # the path it replaces
+    ref_dx = dev(du)
+    rg, rb = ops.bn_bwd(ref_dx, dev(y), *aff, dev(gamma), dev(parts))
+    ref_du, ref_parts = ops.conv4s2_dgrad_bnstat(ref_dx, wp, dev(y_below), aff_below)
+    assert rel_err(dg, rg) < 1e-6 and rel_err(db, rb) < 1e-6
+    dx64 = sc * (dz - dz.sum(dim=(0, 1, 2)) / M - xhat * (dz * xhat).sum(dim=(0, 1, 2)) / M)
+    assert rel_err(got_dx, dx64) < 2e-6 and rel_err(ref_dx, dx64) < 2e-6
+    assert rel_err(got_du, ref_du) < 2e-6
+    assert rel_err(got_parts.double().sum(0), ref_parts.double().sum(0)) < 2e-5
+
+
 # ------------------------------------------------------------------ data gradient + BatchNorm-backward statistics
 @pytest.mark.parametrize('kind,N,H,Cin,Cout', [('conv', 5, 32, 16, 32), ('conv', 3, 64, 1, 16), ('conv', 3, 64, 1, 32),
                                                ('conv', 4, 32, 32, 64), ('conv', 2, 64, 32, 64),

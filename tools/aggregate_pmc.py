@@ -21,9 +21,10 @@ def bench_label(name):
     if m:       # <tile, mode, single input channel, bf16 operands, fused BatchNorm-backward statistics>
         return f"conv_fwd_kernel<T{m.group(1)},{'deconv' if m.group(2) == '1' else 'conv'}" \
                f"{',c1' if m.group(3) == 'true' else ''}{',bnstat' if m.group(5) == 'true' else ''}>"
-    m = re.match(r'void (deconv|conv)_rows_kernel<(\d+), (\d+), \d+, (true|false), (true|false)>', name)
+    m = re.match(r'void (deconv|conv)_rows_kernel<(\d+), (\d+), \d+, (true|false), (true|false)(?:, (true|false))?>', name)
     if m:
-        return f"{m.group(1)}_rows_kernel<{m.group(2)},{m.group(3)}{',bnstat' if m.group(5) == 'true' else ''}>"
+        return f"{m.group(1)}_rows_kernel<{m.group(2)},{m.group(3)}{',bnstat' if m.group(5) == 'true' else ''}" \
+               f"{',bnin' if m.group(6) == 'true' else ''}>"
     m = re.match(r'void conv_c1_kernel<\d+, (true|false)>', name)
     if m:
         return 'conv_c1_kernel' + (',bnstat' if m.group(1) == 'true' else '')
