@@ -139,6 +139,8 @@ class KernelTimer:
             N, H, W, Cin = x.shape
             Cout = wp.shape[1]
             fl = 2.0 * N * 4 * H * W * Cout * 4 * Cin
+            if (Cin, Cout, W) == (128, 64, 8):
+                return "deconv_rows8_kernel<128>", fl, 'flop'
             if (Cin, Cout) in ((32, 16), (64, 32)) and 16 <= W <= 32:   # few channels: rows through an LDS ring
                 return f"deconv_rows_kernel<{Cin},{Cout}>", fl, 'flop'
             return f"conv_fwd_kernel<{tile(Cout, N * H * W, 4)},deconv>", fl, 'flop'

@@ -695,6 +695,170 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
   }
 }
 
+// The same row-ring scheme one size up (Cin*Cout <= 8192, e.g. 128 -> 64 on 8-pixel-wide frames): a
+// phase's filter no longer fits one wave, so a workgroup takes ONE sub-pixel phase (blockIdx.x & 3;
+// the four workgroups of a row run share their input rows through L2) and its four waves hold sixteen
+// output channels each ([16][4 taps][Cin] = 128 registers per lane at Cin = 128).  A group of sixteen
+// pixels is two rows of eight, so the row a lane reads depends on the lane: rows outside the frame are
+// redirected to a ninth, all-zero slot instead of being skipped.
+template <int CIN, int WAVES_PER_EU, bool XF, bool BNS>
+__global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows8_kernel(ConvArgs g) {
+  constexpr int COUT = 64, W = 8, NU = CIN / 16;
+  constexpr int PS = CIN + 4, C4 = CIN / 4;
+  constexpr int SLOT = (W + 2) * PS;
+  constexpr int NLD = (W * C4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float ring[9 * SLOT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int phase = blockIdx.x & 3, ph = phase >> 1, pw = phase & 1;
+  const int bx = blockIdx.x >> 2, gx = gridDim.x >> 2;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int H = g.H;
+  // component m of wa[t][u] multiplies channel 16u + 4kq + m of tap t into output channel 16 wave + i16
+  f32x4 wa[4][NU];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const f32x4 w = ldg4(g.wp + (((int64_t)phase * COUT + 16 * wave + i16) * 4 + t) * CIN + 16 * u + 4 * kq);
+      wa[t][u] = g.round_bf16 ? round_bf16(w) : w;
+    }
+  const int lc4 = threadIdx.x % C4;
+  f32x4 sc = (f32x4){1.f, 1.f, 1.f, 1.f}, sh = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float slope = g.in_act == DVAE_ACT_LRELU ? LRELU_SLOPE : 1.f;
+  if (XF && g.in_scale) {
+    sc = ldg4(g.in_scale + 4 * lc4);
+    sh = ldg4(g.in_shift + 4 * lc4);
+  }
+  f32x4 bsc, bsh, bmu, bis;
+  if (BNS) {
+    bsc = ldg4(g.bn_scale + 16 * wave + 4 * kq);
+    bsh = ldg4(g.bn_shift + 16 * wave + 4 * kq);
+    bmu = ldg4(g.bn_mean + 16 * wave + 4 * kq);
+    bis = ldg4(g.bn_invstd + 16 * wave + 4 * kq);
+  }
+  f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // zero pixels left and right of the eight row slots, and the whole ninth slot
+  for (int i = threadIdx.x; i < 8 * 2 * PS; i += 256) {
+    const int slot = i / (2 * PS), r = i % (2 * PS);
+    ring[slot * SLOT + (r < PS ? 0 : (W + 1) * PS) + r % PS] = 0.f;
+  }
+  for (int i = threadIdx.x; i < SLOT; i += 256) ring[8 * SLOT + i] = 0.f;
+
+  // Input rows are numbered over the whole batch; a step takes the row pair (2p, 2p+1), which never
+  // straddles two frames (H is even), and reads rows 2p-1 .. 2p+2.  gx workgroups per phase, one per
+  // partial-statistics row; the first g.mtiles of them share out the pairs in contiguous runs.
+  const int64_t rows = g.M >> 3, pairs = rows >> 1;
+  const int64_t per = (pairs + g.mtiles - 1) / g.mtiles;
+  const int64_t p0 = bx < g.mtiles ? bx * per : pairs;
+  const int64_t p1 = p0 + per < pairs ? p0 + per : pairs;
+  constexpr int row_pieces = W * C4;
+
+  auto fetch = [&](int64_t row, f32x4 (&raw)[NLD]) {
+    const bool rok = row >= 0 && row < rows;
+    const float* src = g.x + (rok ? row : 0) * (int64_t)row_pieces * 4;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int f = threadIdx.x + 256 * j;
+      raw[j] = ldg4(src + 4 * (rok && f < row_pieces ? f : 0));
+    }
+  };
+  auto deposit = [&](int64_t row, const f32x4 (&raw)[NLD]) {
+    float* dst = ring + (row & 7) * SLOT;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int f = threadIdx.x + 256 * j;
+      if (f < row_pieces) {
+        f32x4 v = raw[j];
+        if (XF) {
+          const f32x4 z = v * sc + sh;       // slope <= 1: lrelu(z) = max(z, slope z)
+          const f32x4 zs = z * slope;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(z[e], zs[e]);
+        }
+        if (g.round_bf16) v = round_bf16(v);
+        *reinterpret_cast<f32x4*>(dst + (1 + f / C4) * PS + 4 * lc4) = v;
+      }
+    }
+  };
+  f32x4 rawa[NLD], rawb[NLD];
+  if (p0 < p1) {
+    fetch(2 * p0 - 1, rawa);
+    fetch(2 * p0, rawb);
+    deposit(2 * p0 - 1, rawa);
+    deposit(2 * p0, rawb);
+    fetch(2 * p0 + 1, rawa);
+    fetch(2 * p0 + 2, rawb);
+    deposit(2 * p0 + 1, rawa);
+    deposit(2 * p0 + 2, rawb);
+  }
+  __syncthreads();
+  const int b = i16 & 7;
+  for (int64_t p = p0; p < p1; ++p) {
+    fetch(2 * p + 3, rawa);
+    fetch(2 * p + 4, rawb);
+    const int64_t arow = 2 * p + (i16 >> 3);                // this lane's input row
+    const int a = (int)arow & (H - 1);
+    const int64_t orow = (2 * arow + ph) * (2 * W) + 2 * b + pw;
+    f32x4 yv;
+    if (BNS) yv = ldg4(g.bn_y + orow * COUT + 16 * wave + 4 * kq);
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+      const int ia = a + ph - th;
+      const bool inside = ia >= 0 && ia < H;
+      const float* rowp = ring + (inside ? (int)((arow + ph - th) & 7) : 8) * SLOT;
+      f32x4 xv[2][NU];
+#pragma unroll
+      for (int tw = 0; tw < 2; ++tw)
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+          xv[tw][u] = *reinterpret_cast<const f32x4*>(rowp + (1 + b + pw - tw) * PS + 16 * u + 4 * kq);
+#pragma unroll
+      for (int tw = 0; tw < 2; ++tw)
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[2 * th + tw][u][e], xv[tw][u][e], acc[e & 1], 0, 0, 0);
+    }
+    // D: row = output channel 16 wave + 4kq + e, column = pixel i16
+    const f32x4 v = acc[0] + acc[1];
+    *reinterpret_cast<f32x4*>(g.y + orow * COUT + 16 * wave + 4 * kq) = v;
+    if (!BNS) {
+      s1 += v;
+      s2 += v * v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = fmaf(yv[e], bsc[e], bsh[e]);
+        const float dz = z > 0.f ? v[e] : v[e] * LRELU_SLOPE;
+        s1[e] += dz;
+        s2[e] += dz * ((yv[e] - bmu[e]) * bis[e]);
+      }
+    }
+    deposit(2 * p + 3, rawa);       // slots of rows 2p+3, 2p+4 are not among the four this step reads
+    deposit(2 * p + 4, rawb);
+    __syncthreads();
+  }
+  if (g.stats) {
+    const int64_t part = (int64_t)phase * gx + bx;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a1 = s1[e], a2 = s2[e];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        a1 += __shfl_xor(a1, o);
+        a2 += __shfl_xor(a2, o);
+      }
+      if (i16 == 0) {
+        g.stats[(part * 2 + 0) * COUT + 16 * wave + 4 * kq + e] = a1;
+        g.stats[(part * 2 + 1) * COUT + 16 * wave + 4 * kq + e] = a2;
+      }
+    }
+  }
+}
+
 // Stride-2 convolution with few channels (Cin <= 32) on frames at least 32 pixels wide, by the same
 // scheme: a wave keeps the filter of sixteen output channels [16][16 taps][Cin] in registers (the
 // workgroup has Cout/16 waves), input rows go through an LDS ring once (eight slots: four rows feed an
@@ -948,6 +1112,19 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   ROWS_LAUNCH(32, 16, 2, 4)
   ROWS_LAUNCH(64, 32, 2, 2)
 #undef ROWS_LAUNCH
+  if (MODE == 1 && g.Cin == 128 && g.Cout == 64 && g.W == 8 && g.H >= 2 && aligned16(g.y) &&
+      (!bns || aligned16(g.bn_y)) && (!g.in_scale || (aligned16(g.in_scale) && aligned16(g.in_shift)))) {
+    const unsigned gx = (unsigned)(conv_parts_written(g.M, phases) / phases);
+    g.mtiles = (int)gx < 128 ? (int)gx : 128;      // 4 phases x 128 = two workgroups per compute unit
+    const bool xf = g.in_scale != nullptr || g.in_act != DVAE_ACT_NONE;
+    const dim3 grid(gx * 4);
+    if (bns && xf) hipLaunchKernelGGL((deconv_rows8_kernel<128, 2, true, true>), grid, dim3(256), 0, stream, g);
+    else if (bns) hipLaunchKernelGGL((deconv_rows8_kernel<128, 2, false, true>), grid, dim3(256), 0, stream, g);
+    else if (xf) hipLaunchKernelGGL((deconv_rows8_kernel<128, 2, true, false>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((deconv_rows8_kernel<128, 2, false, false>), grid, dim3(256), 0, stream, g);
+    DVAE_LAUNCH_CHECK(name);
+    return 0;
+  }
 #define CONV_ROWS_LAUNCH(CI, CO, WPE, RESIDENT)                                                           \
   if (MODE == 0 && !bf && g.Cin == CI && g.Cout == CO && g.W >= 32 && g.W <= 64 && g.H >= 2 &&            \
       aligned16(g.y) && (!bns || aligned16(g.bn_y)) &&                                                    \

@@ -224,7 +224,9 @@ def test_conv4s2_fwd(ops, N, H, Cin, Cout):
 # share out the rows (N=70 at 64->32); the same channels on smaller frames take the tiled kernel
 DECONV_CASES = [(3, 4, 64, 32), (2, 8, 32, 16), (3, 16, 16, 8), (2, 32, 8, 4), (6, 4, 256, 128), (70, 4, 4, 36),
                 (3, 2, 64, 32), (5, 2, 32, 16), (100, 32, 32, 16), (40, 32, 64, 32), (3, 16, 32, 16), (2, 16, 64, 32),
-                (300, 16, 32, 16), (70, 32, 64, 32)]
+                (300, 16, 32, 16), (70, 32, 64, 32),
+                # 128 -> 64 on 8-wide frames: one phase per workgroup, two rows per group of sixteen pixels
+                (3, 8, 128, 64), (300, 8, 128, 64)]
 
 
 @pytest.mark.parametrize('N,H,Cin,Cout', DECONV_CASES)
@@ -545,7 +547,7 @@ def test_dgrad_that_applies_the_bn_backward_of_its_input(ops, N, H):
                                                ('deconv', 6, 4, 256, 128), ('deconv', 70, 4, 4, 36),
                                                ('deconv', 5, 2, 32, 16), ('deconv', 100, 32, 32, 16),
                                                ('deconv', 40, 32, 64, 32), ('deconv', 3, 16, 32, 16),
-                                               ('deconv', 2, 16, 64, 32)])
+                                               ('deconv', 2, 16, 64, 32), ('deconv', 5, 8, 128, 64)])
 def test_dgrad_with_fused_bn_backward_statistics(ops, kind, N, H, Cin, Cout):
     """The data-gradient kernels with the BatchNorm-backward reduction folded into their epilogue: the
     gradient they write is the plain kernel's, the partial rows sum to sum(dz) and sum(dz*xhat), and

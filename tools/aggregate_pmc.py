@@ -28,6 +28,9 @@ def bench_label(name):
     m = re.match(r'void conv_c1_kernel<\d+, (true|false)>', name)
     if m:
         return 'conv_c1_kernel' + (',bnstat' if m.group(1) == 'true' else '')
+    m = re.match(r'void deconv_rows8_kernel<(\d+), \d+, (true|false), (true|false)>', name)
+    if m:
+        return f"deconv_rows8_kernel<{m.group(1)}{',bnstat' if m.group(3) == 'true' else ''}>"
     m = re.match(r'void wgrad_rows_kernel<(\d+), (\d+),', name)
     if m:
         return f'wgrad_rows_kernel<{m.group(1)},{m.group(2)}>'
