@@ -215,6 +215,7 @@ class KernelTimer:
         self._wrap('recon_loss_bwd', loss_bwd_key)
         self._wrap('lstm_step_fwd', lstm_key)
         self._wrap('skinny_gemm_nt', skinny_key)
+        self._wrap('lstm_bwd_step', lambda dg_t, wt, *r: ('lstm_bwd_step_kernel', 2.0 * dg_t.shape[0] * wt.shape[0] * dg_t.shape[1], 'flop'))
 
     def remove(self):
         for n, f in self.saved.items():

@@ -257,6 +257,93 @@ __global__ void __launch_bounds__(64 * SK_WAVES) skinny_gemm_nt_kernel(SkinnyArg
   }
 }
 
+// One whole backward step in a launch: the skinny product above finishes dh_{t-1} (+= dG_t * W), and the
+// thread that owns an element of it takes it straight through the cell's pointwise backward of step
+// t-1 (what lstm_bwd_pointwise_kernel does), writing that step's gate gradients and dc.  The
+// recurrence's critical path is then one kernel per time step instead of two.
+struct LstmBwdStepArgs {
+  SkinnyArgs mm;                 // out = dh_{t-1} [B,H], accumulated in place
+  const float* gates;            // activated gates of step t-1 [B,4H]
+  const float* c_prev; int64_t ld_cprev;   // c_{t-2} (nullptr: zero state)
+  const float* c; int64_t ld_c;            // c_{t-1}
+  const float* dc; int64_t ld_dc;          // dc carried into step t-1
+  float* dgates;                 // [B,4H] out
+  float* dc_prev; int64_t ld_dcprev;       // out
+};
+
+__global__ void __launch_bounds__(64 * SK_WAVES) lstm_bwd_step_kernel(LstmBwdStepArgs a) {
+  __shared__ float red[SK_WAVES * 16 * SK_RED_LD];
+  const SkinnyArgs& g = a.mm;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int64_t n0 = (int64_t)blockIdx.x * 16, b0 = (int64_t)blockIdx.y * 16;
+  const bool rowok = b0 + i < g.B, colok = n0 + i < g.N;
+  const float* ap = g.a + (rowok ? b0 + i : g.B - 1) * g.ld_a;
+  const float* bp = g.wt + (colok ? n0 + i : g.N - 1) * g.ld_wt;
+  // everything the owner of an output needs besides the product is requested first
+  const int orow = (threadIdx.x >> 4) & 15, ocol = threadIdx.x & 15;
+  const bool owner = threadIdx.x < 256 && b0 + orow < g.B && n0 + ocol < g.N;
+  const int64_t b = owner ? b0 + orow : 0, j = owner ? n0 + ocol : 0, H = g.N;
+  float* const op = g.out + b * g.ld_out + j;
+  const float prev = *op;
+  const float* gt = a.gates + b * 4 * H;
+  const float ig = gt[j], fg = gt[H + j], gg = gt[2 * H + j], og = gt[3 * H + j];
+  const float cv = a.c[b * a.ld_c + j];
+  const float dcin = *(a.dc ? a.dc + b * a.ld_dc + j : a.c);
+  const float cpv = *(a.c_prev ? a.c_prev + b * a.ld_cprev + j : a.c);
+
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int64_t k0 = (int64_t)wave * 16 * SK_NF; k0 < g.K; k0 += 16 * SK_NF * SK_WAVES) {
+    f32x4 av[SK_NF], bv[SK_NF];
+    frag_load<SK_NF>(ap, rowok, k0 + 4 * q, 16, g.K, av);
+    frag_load<SK_NF>(bp, colok, k0 + 4 * q, 16, g.K, bv);
+#pragma unroll
+    for (int f = 0; f < SK_NF; ++f) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][0], bv[f][0], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][1], bv[f][1], acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][2], bv[f][2], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][3], bv[f][3], acc2, 0, 0, 0);
+    }
+  }
+  acc += acc2;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * q + r) * SK_RED_LD + i] = acc[r];
+  __syncthreads();
+  if (owner) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) s += red[(w * 16 + orow) * SK_RED_LD + ocol];
+    const float dhv = s + prev;
+    *op = dhv;
+    const float tc = tanhf(cv);
+    const float dct = (a.dc ? dcin : 0.f) + dhv * og * (1.f - tc * tc);
+    const float cp = a.c_prev ? cpv : 0.f;
+    float* dg = a.dgates + b * 4 * H;
+    dg[j] = dct * gg * ig * (1.f - ig);
+    dg[H + j] = dct * cp * fg * (1.f - fg);
+    dg[2 * H + j] = dct * ig * (1.f - gg * gg);
+    dg[3 * H + j] = dhv * tc * og * (1.f - og);
+    a.dc_prev[b * a.ld_dcprev + j] = dct * fg;
+  }
+}
+
+extern "C" int dvae_lstm_bwd_step_f32(const float* dg_t, int64_t ld_dg, const float* wt, int64_t ld_wt, float* dh_prev,
+                                      int64_t ld_dh, const float* dc, int64_t ld_dc, const float* gates,
+                                      const float* c_prev, int64_t ld_cprev, const float* c, int64_t ld_c,
+                                      float* dgates, float* dc_prev, int64_t ld_dcprev, int64_t B, int64_t H,
+                                      int64_t K, dvae_stream_t stream) {
+  DVAE_REQUIRE(B > 0 && H > 0 && K > 0, "lstm_bwd_step: empty");
+  DVAE_REQUIRE(dg_t && wt && dh_prev && gates && c && dgates && dc_prev, "lstm_bwd_step: null argument");
+  DVAE_REQUIRE(K % 4 == 0 && ld_dg % 4 == 0 && ld_wt % 4 == 0, "lstm_bwd_step: K, ld_dg, ld_wt must be multiples of 4");
+  DVAE_REQUIRE(aligned16(dg_t) && aligned16(wt), "lstm_bwd_step: 16-byte alignment");
+  LstmBwdStepArgs a{SkinnyArgs{dg_t, ld_dg, wt, ld_wt, dh_prev, ld_dh, B, H, K, 1},
+                    gates, c_prev, ld_cprev, c, ld_c, dc, ld_dc, dgates, dc_prev, ld_dcprev};
+  const dim3 grid((unsigned)ceil_div64(H, 16), (unsigned)ceil_div64(B, 16));
+  hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(64 * SK_WAVES), 0, ST(stream), a);
+  DVAE_LAUNCH_CHECK("lstm_bwd_step");
+  return 0;
+}
+
 extern "C" int dvae_skinny_gemm_nt_f32(const float* a, int64_t ld_a, const float* wt, int64_t ld_wt, float* out,
                                        int64_t ld_out, int64_t B, int64_t N, int64_t K, int accumulate,
                                        dvae_stream_t stream) {

@@ -75,6 +75,7 @@ SIGNATURES = {
     'dvae_lstm_step_fwd_f32': (I, [P, L, P, L, P, L, P, L, P, L, P, P, P, P, P, L, P, L, L, L, P]),
     'dvae_lstm_step_bwd_pointwise_f32': (I, [P, L, P, L, P, P, L, P, L, P, P, L, L, L, P]),
     'dvae_skinny_gemm_nt_f32': (I, [P, L, P, L, P, L, L, L, L, I, P]),
+    'dvae_lstm_bwd_step_f32': (I, [P, L, P, L, P, L, P, L, P, P, L, P, L, P, P, L, L, L, L, P]),
     'dvae_grad_norm_ws_floats': (L, [L, POINTER(c_int64)]),
     'dvae_grad_norm_f32': (I, [L, POINTER(c_void_p), POINTER(c_int64), F, P, P, P]),
     'dvae_scale_tensors_f32': (I, [L, POINTER(c_void_p), POINTER(c_int64), P, P]),

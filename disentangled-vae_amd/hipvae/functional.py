@@ -401,11 +401,16 @@ class LSTMEncoder(torch.autograd.Function):
                         sl = slice(d * H, (d + 1) * H)
                         dc = dcs[d]
                         with lanes.lane(d):
-                            ops.lstm_step_bwd_pointwise(dh[t][:, sl], None if i == T - 1 else dc[(i + 1) & 1],
-                                                        gates[d, t], None if tp is None else cseq[d, tp], cseq[d, t],
-                                                        dgs[d][t], dc[i & 1])
+                            if i == T - 1:                        # the last step starts the chain
+                                ops.lstm_step_bwd_pointwise(dh[t][:, sl], None, gates[d, t],
+                                                            None if tp is None else cseq[d, tp], cseq[d, t],
+                                                            dgs[d][t], dc[i & 1])
                             if tp is not None:
-                                ops.skinny_gemm_nt(dgs[d][t], w_hh_t[d], dh[tp][:, sl], True)
+                                # dh[tp] += dG_t W_hh, then straight through the cell of step tp
+                                tpp = None if i == 1 else (tp + 1 if d == 1 else tp - 1)
+                                ops.lstm_bwd_step(dgs[d][t], w_hh_t[d], dh[tp][:, sl], dc[i & 1], gates[d, tp],
+                                                  None if tpp is None else cseq[d, tpp], cseq[d, tp],
+                                                  dgs[d][tp], dc[(i - 1) & 1])
             for d in range(D):
                 k = (l * D + d) * 4
                 w_ih = weights[k].contiguous()
@@ -498,13 +503,21 @@ class LSTMDecoder(torch.autograd.Function):
         w_ih_t = [weights[4 * l].t().contiguous() for l in range(L)]
         w_hh_t = [weights[4 * l + 1].t().contiguous() for l in range(L)]
         w_comb_t = (w_ih_t[0] + w_hh_t[0]) if (L == 1 and T > 1) else None
+        fused = w_comb_t is not None      # single layer: one launch per step (product + next pointwise)
         for t in range(T - 1, -1, -1):
             for l in range(L - 1, -1, -1):
                 w_ih, w_hh = w_ih_t[l], w_hh_t[l]
                 c_prev = c0[:, l * H:(l + 1) * H] if t == 0 else cs[l, t - 1]
                 dc_in = None if t == T - 1 else dcbuf[l][(t + 1) & 1]
                 dc_out = dc0[:, l * H:(l + 1) * H] if t == 0 else dcbuf[l][t & 1]
-                ops.lstm_step_bwd_pointwise(dhs[l, t], dc_in, gates[l, t], c_prev, cs[l, t], dg[l, t], dc_out)
+                if not fused or t == T - 1:
+                    ops.lstm_step_bwd_pointwise(dhs[l, t], dc_in, gates[l, t], c_prev, cs[l, t], dg[l, t], dc_out)
+                if fused and t > 0:
+                    # dh_{t-1} += dG_t (W_ih + W_hh), then straight through the cell of step t-1
+                    ops.lstm_bwd_step(dg[0, t], w_comb_t, dhs[0, t - 1], dc_out, gates[0, t - 1],
+                                      c0[:, :H] if t == 1 else cs[0, t - 2], cs[0, t - 1], dg[0, t - 1],
+                                      dc0[:, :H] if t == 1 else dcbuf[0][(t - 1) & 1])
+                    continue
                 # recurrent path -> h_{t-1} of this layer
                 rec_target = dh0[:, l * H:(l + 1) * H] if t == 0 else dhs[l, t - 1]
                 rec_acc = t > 0

@@ -482,6 +482,20 @@ def lstm_step_bwd_pointwise(dh, dc, gates, c_prev, c, dgates, dc_prev):
           'lstm_step_bwd_pointwise')
 
 
+def lstm_bwd_step(dg_t, wt, dh_prev, dc, gates, c_prev, c, dgates, dc_prev):
+    """dh_prev += dg_t @ wt^T, then the pointwise backward of the step dh_prev belongs to (arguments as in
+    lstm_step_bwd_pointwise, for that step)."""
+    _chk2(dg_t, wt, dh_prev, dc, gates, c_prev, c, dgates, dc_prev)
+    B, K = dg_t.shape
+    H = wt.shape[0]
+    assert wt.shape[1] == K and dh_prev.shape == (B, H) and gates.is_contiguous() and dgates.is_contiguous()
+    assert dg_t.stride(1) == 1 and wt.stride(1) == 1 and dh_prev.stride(1) == 1
+    ld = lambda t: 0 if t is None else t.stride(0)
+    check(lib.dvae_lstm_bwd_step_f32(_p(dg_t), dg_t.stride(0), _p(wt), wt.stride(0), _p(dh_prev), dh_prev.stride(0),
+                                     _p(dc), ld(dc), _p(gates), _p(c_prev), ld(c_prev), _p(c), ld(c), _p(dgates),
+                                     _p(dc_prev), ld(dc_prev), B, H, K, _stream()), 'lstm_bwd_step')
+
+
 def skinny_gemm_nt(a: Tensor, wt: Tensor, out: Tensor, accumulate: bool):
     """out[B,N] (+)= a[B,K] @ wt[N,K]^T; rows of a, wt and out may be strided (unit stride inside a row)."""
     _chk2(a, wt, out)

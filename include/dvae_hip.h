@@ -254,6 +254,15 @@ int dvae_lstm_step_bwd_pointwise_f32(const float* dh, int64_t ld_dh, const float
                                      const float* gates, const float* c_prev, int64_t ld_cprev,
                                      const float* c, int64_t ld_c, float* dgates, float* dc_prev,
                                      int64_t ld_dcprev, int64_t B, int64_t H, dvae_stream_t stream);
+/* One whole backward step of the recurrence in a launch: dh_prev [B,H] += dg_t [B,K] * wt [H,K]^T
+ * (K = 4H; wt is W_hh transposed, or (W_ih + W_hh)^T for a single-layer decoder), and every finished
+ * element goes straight through the pointwise backward of step t-1 as in
+ * dvae_lstm_step_bwd_pointwise_f32 (dc, gates, c_prev, c of step t-1 -> dgates, dc_prev). */
+int dvae_lstm_bwd_step_f32(const float* dg_t, int64_t ld_dg, const float* wt, int64_t ld_wt, float* dh_prev,
+                           int64_t ld_dh, const float* dc, int64_t ld_dc, const float* gates,
+                           const float* c_prev, int64_t ld_cprev, const float* c, int64_t ld_c,
+                           float* dgates, float* dc_prev, int64_t ld_dcprev, int64_t B, int64_t H,
+                           int64_t K, dvae_stream_t stream);
 /* Skinny GEMM of the recurrence's backward step, dh_{t-1} (+)= dG_t * W with W handed over transposed:
  * out[B,N] (+)= a[B,K] * wt[N,K]^T, every row with its own stride (floats).  Latency-oriented: 16x16
  * output tiles, K split over the waves of a workgroup, operands loaded straight into MFMA registers.

@@ -427,6 +427,25 @@ def test_lstm_step_bwd(ops):
     assert rel_err(out, dh + dp @ w_hh + dp @ w_ih) < 5e-6
 
 
+@pytest.mark.parametrize('B,H', [(6, 32), (37, 24), (256, 256)])
+def test_lstm_bwd_step_is_product_then_pointwise(ops, B, H):
+    """The one-launch backward step against the two kernels it fuses."""
+    dg_t, w = dev(rnd(B, 4 * H, seed=76)), dev(rnd(4 * H, H, seed=77, scale=0.2))
+    wt = w.t().contiguous()
+    dh0, dc = rnd(B, H, seed=78), dev(rnd(B, H, seed=79))
+    gates = dev(torch.sigmoid(rnd(B, 4 * H, seed=80)))
+    c_prev, c = dev(rnd(B, H, seed=81)), dev(rnd(B, H, seed=82))
+    for cp, dcin in ((c_prev, dc), (None, None)):
+        ref_dh = dev(dh0)
+        ops.skinny_gemm_nt(dg_t, wt, ref_dh, True)
+        ref_dg, ref_dc = torch.empty(B, 4 * H, device='cuda'), torch.empty(B, H, device='cuda')
+        ops.lstm_step_bwd_pointwise(ref_dh, dcin, gates, cp, c, ref_dg, ref_dc)
+        got_dh = dev(dh0)
+        got_dg, got_dc = torch.empty(B, 4 * H, device='cuda'), torch.empty(B, H, device='cuda')
+        ops.lstm_bwd_step(dg_t, wt, got_dh, dcin, gates, cp, c, got_dg, got_dc)
+        assert torch.equal(got_dh, ref_dh) and torch.equal(got_dg, ref_dg) and torch.equal(got_dc, ref_dc)
+
+
 @pytest.mark.parametrize('B,N,K', [(32, 256, 1024), (256, 256, 1024), (70, 36, 132), (1, 4, 4), (17, 3, 2052)])
 def test_skinny_gemm(ops, B, N, K):
     a, w = rnd(B, K, seed=74), rnd(K, N, seed=75)
