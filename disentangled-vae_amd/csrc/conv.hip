@@ -1770,8 +1770,137 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) wgrad_rows_kernel(WgradArgs
           slab[(int64_t)(16 * rb + 4 * kq + e) * g.NC + (4 * (dh0 + dl) + dw) * C2 + 16 * cb + i16] = acc[dl][dw][cb][e];
 }
 
+// The same for C1 = 128, C2 = 64 on 8-pixel-wide P (the gradient is four times what one workgroup's
+// accumulators hold): a workgroup takes one filter row dh (blockIdx.x & 3), i.e. the columns of taps
+// 4dh .. 4dh+3, so for a P row it needs exactly one Q row (2a-1+dh).  A step is a pair of P rows
+// (sixteen pixels = one K group); Q rows that fall outside the frame are deposited as zeros.  Wave w owns
+// gradient rows 32w .. 32w+31.  The four workgroups of a split fill one slab between them.
+template <bool XP, bool XQ>
+__global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
+  constexpr int C1 = 128, C2 = 64, Ws = 8, WQ = 16, NCB = C2 / 16;
+  constexpr int PSP = C1 + 4, PSQ = C2 + 2, P4 = C1 / 4, Q4 = C2 / 4;
+  constexpr int PROW = Ws * PSP, QROW = (WQ + 2) * PSQ;
+  __shared__ __attribute__((aligned(16))) float pbuf[2][2][PROW];
+  __shared__ __attribute__((aligned(16))) float qbuf[2][2][QROW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int dh = blockIdx.x & 3, z = blockIdx.x >> 2, nsplit = gridDim.x >> 2;
+  const int Hs = g.Hs;
+
+  const int lp4 = threadIdx.x % P4, lq4 = threadIdx.x % Q4;
+  f32x4 psc = (f32x4){1.f, 1.f, 1.f, 1.f}, psh = (f32x4){0.f, 0.f, 0.f, 0.f}, qsc = psc, qsh = psh;
+  const float pslope = g.p_act == DVAE_ACT_LRELU ? LRELU_SLOPE : 1.f;
+  const float qslope = g.q_act == DVAE_ACT_LRELU ? LRELU_SLOPE : 1.f;
+  if (XP && g.p_scale) {
+    psc = ldg4(g.p_scale + 4 * lp4);
+    psh = ldg4(g.p_shift + 4 * lp4);
+  }
+  if (XQ && g.q_scale) {
+    qsc = ldg4(g.q_scale + 4 * lq4);
+    qsh = ldg4(g.q_shift + 4 * lq4);
+  }
+  // zero pixels left (column -1) and right (column WQ) of the four Q row buffers
+  for (int i = threadIdx.x; i < 4 * 2 * PSQ; i += 256) {
+    const int slot = i / (2 * PSQ), r = i % (2 * PSQ);
+    (&qbuf[0][0][0])[slot * QROW + (r < PSQ ? 0 : (WQ + 1) * PSQ) + r % PSQ] = 0.f;
+  }
+  f32x4 acc[2][4][NCB];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // P rows are numbered over the whole batch; a pair (2p, 2p+1) never straddles two frames
+  const int64_t rows = g.Mtot >> 3, pairs = rows >> 1;
+  const int64_t per = (pairs + nsplit - 1) / nsplit;
+  const int64_t p0 = z * per;
+  const int64_t p1 = p0 + per < pairs ? p0 + per : pairs;
+
+  auto transform = [](f32x4 v, const f32x4& sc, const f32x4& sh, float slope) {
+    const f32x4 zz = v * sc + sh;         // slope <= 1: lrelu(z) = max(z, slope z)
+    const f32x4 zs = zz * slope;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(zz[e], zs[e]);
+    return v;
+  };
+  // a thread moves one 16-byte piece of each of the pair's two P rows and two Q rows
+  struct Raw {
+    f32x4 p[2], q[2];
+    bool qok[2];
+  };
+  auto fetch = [&](int64_t p, Raw& raw) {
+    const bool pok = p < p1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t prow = 2 * p + h;
+      const int a = (int)prow & (Hs - 1);
+      const int hin = 2 * a - 1 + dh;
+      raw.qok[h] = pok && hin >= 0 && hin < 2 * Hs;
+      raw.p[h] = ldg4(g.P + (pok ? prow * (int64_t)(Ws * C1) : 0) + 4 * threadIdx.x);
+      raw.q[h] = ldg4(g.Q + (raw.qok[h] ? (2 * prow - 1 + dh) * (int64_t)(WQ * C2) : 0) + 4 * threadIdx.x);
+    }
+  };
+  auto deposit = [&](int64_t p, const Raw& raw) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 pv = XP ? transform(raw.p[h], psc, psh, pslope) : raw.p[h];
+      *reinterpret_cast<f32x4*>(&pbuf[p & 1][h][(threadIdx.x / P4) * PSP + 4 * lp4]) = pv;
+      f32x4 qv = XQ ? transform(raw.q[h], qsc, qsh, qslope) : raw.q[h];
+      qv = zero_unless(qv, raw.qok[h]);
+      float* d = &qbuf[p & 1][h][(1 + threadIdx.x / Q4) * PSQ + 4 * lq4];     // 8-byte aligned (PSQ is even)
+      *reinterpret_cast<float2*>(d) = make_float2(qv[0], qv[1]);
+      *reinterpret_cast<float2*>(d + 2) = make_float2(qv[2], qv[3]);
+    }
+  };
+  Raw raw;
+  if (p0 < p1) {
+    fetch(p0, raw);
+    deposit(p0, raw);
+  }
+  __syncthreads();
+  for (int64_t p = p0; p < p1; ++p) {
+    fetch(p + 1, raw);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pos = 4 * kq + e, h = pos >> 3, b = pos & 7;     // this lane's pixel of the K group
+      const float* prow = pbuf[p & 1][h];
+      const float* qrow = qbuf[p & 1][h];
+      float av[2], bv[4][NCB];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) av[r] = prow[b * PSP + 16 * (2 * wave + r) + i16];
+      // Q pixel of (b, dw) is column 2b-1+dw, stored at index 2b+dw
+#pragma unroll
+      for (int dw = 0; dw < 4; ++dw)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) bv[dw][cb] = qrow[(2 * b + dw) * PSQ + 16 * cb + i16];
+#pragma unroll
+      for (int dw = 0; dw < 4; ++dw)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+            acc[r][dw][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[dw][cb], acc[r][dw][cb], 0, 0, 0);
+    }
+    if (p + 1 < p1) deposit(p + 1, raw);     // the other buffer: nobody reads it during this step
+    __syncthreads();
+  }
+  // D: row = c1 16(2 wave + r) + 4kq + e, column = c2 16cb + i16 of tap 4dh + dw
+  float* slab = g.slab + (int64_t)z * C1 * g.NC;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int dw = 0; dw < 4; ++dw)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          slab[(int64_t)(16 * (2 * wave + r) + 4 * kq + e) * g.NC + (4 * dh + dw) * C2 + 16 * cb + i16] = acc[r][dw][cb][e];
+}
+
 struct WgradPlan {
-  int bm;       // 32, 64 or 128; 0 = single-channel streaming kernel; -1 = row-ring kernel (few channels)
+  int bm;       // 32, 64 or 128; 0 = single-channel streaming kernel; -1 / -2 = row-ring kernels
   int64_t tm, tn;
   int split, ktiles_per_split;
 };
@@ -1789,6 +1918,15 @@ static WgradPlan wgrad_plan(int64_t Mtot, int64_t Ws, int64_t C1, int64_t C2) {
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     p.split = (int)blocks;
+    p.ktiles_per_split = 0;
+    return p;
+  }
+  if (C1 == 128 && C2 == 64 && Ws == 8 && Mtot >= 16 && dvae_mfma_precision() == DVAE_PRECISION_F32) {
+    // four workgroups (filter rows) per slab; 4 x 128 = two workgroups per compute unit
+    p.bm = -2;
+    p.tm = p.tn = 1;
+    const int64_t pairs = Mtot / 16;
+    p.split = (int)(pairs < 128 ? pairs : 128);
     p.ktiles_per_split = 0;
     return p;
   }
@@ -1843,7 +1981,17 @@ extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, cons
   const WgradPlan p = wgrad_plan(g.Mtot, Ws, C1, C2);
   g.ktiles_per_split = p.ktiles_per_split;
   hipStream_t s = ST(stream);
-  if (p.bm == -1) {
+  if (p.bm == -2) {
+    DVAE_REQUIRE(Hs >= 2, "conv4s2_wgrad: Hs must be at least 2 at this shape");
+    DVAE_REQUIRE((!p_scale || (aligned16(p_scale) && aligned16(p_shift))) && (!q_scale || (aligned16(q_scale) && aligned16(q_shift))),
+                 "conv4s2_wgrad: scale/shift vectors must be 16-byte aligned");
+    const dim3 grid((unsigned)p.split * 4);
+    const bool xp = p_scale != nullptr || p_act != DVAE_ACT_NONE, xq = q_scale != nullptr || q_act != DVAE_ACT_NONE;
+    if (xp && xq) hipLaunchKernelGGL((wgrad_rows8_kernel<true, true>), grid, dim3(256), 0, s, g);
+    else if (xp) hipLaunchKernelGGL((wgrad_rows8_kernel<true, false>), grid, dim3(256), 0, s, g);
+    else if (xq) hipLaunchKernelGGL((wgrad_rows8_kernel<false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((wgrad_rows8_kernel<false, false>), grid, dim3(256), 0, s, g);
+  } else if (p.bm == -1) {
     DVAE_REQUIRE((!p_scale || (aligned16(p_scale) && aligned16(p_shift))) && (!q_scale || (aligned16(q_scale) && aligned16(q_shift))),
                  "conv4s2_wgrad: scale/shift vectors must be 16-byte aligned");
     const dim3 grid((unsigned)p.split);
