@@ -149,6 +149,8 @@ class KernelTimer:
             N, Hs, Ws, C1 = P.shape
             C2 = Q.shape[3]
             fl = 2.0 * N * Hs * Ws * C1 * 16 * C2
+            if (C1, C2, Ws, Hs) == (256, 128, 4, 4) and N >= 32:
+                return "wgrad_img4_kernel", fl, 'flop'
             if (C1, C2, Ws) == (128, 64, 8):
                 return "wgrad_rows8_kernel", fl, 'flop'
             if (C1, C2) in ((64, 32), (32, 16)) and Ws in (16, 32):       # few channels: rows through LDS rings

@@ -1899,8 +1899,129 @@ __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
           slab[(int64_t)(16 * (2 * wave + r) + 4 * kq + e) * g.NC + (4 * dh + dw) * C2 + 16 * cb + i16] = acc[r][dw][cb][e];
 }
 
+// And for C1 = 256, C2 = 128 on 4x4 P (sixteen times one workgroup's accumulators): a workgroup takes
+// ONE filter tap (dh, dw), and a step is one whole frame -- its sixteen P pixels are exactly one K
+// group, and the tap needs exactly sixteen of the frame's 8x8 Q pixels, (2a-1+dh, 2b-1+dw), gathered
+// into LDS pixel by pixel (zeros where the tap leaves the frame).  Wave w owns gradient rows
+// 64w .. 64w+63.  The sixteen workgroups of a split are numbered so that they land on one XCD close
+// together in time and share the frame through that XCD's L2.
+template <bool XP, bool XQ>
+__global__ void __launch_bounds__(256, 2) wgrad_img4_kernel(WgradArgs g) {
+  constexpr int C1 = 256, C2 = 128, NCB = C2 / 16;
+  constexpr int PSP = C1 + 4, PSQ = C2 + 4, P4 = C1 / 4, Q4 = C2 / 4;
+  __shared__ __attribute__((aligned(16))) float pbuf[2][16 * PSP];
+  __shared__ __attribute__((aligned(16))) float qbuf[2][16 * PSQ];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int tap = jj & 15, dh = tap >> 2, dw = tap & 3;
+  const int z = (jj >> 4) * 8 + xcd, nsplit = gridDim.x >> 4;
+
+  const int lp4 = threadIdx.x % P4, lq4 = threadIdx.x % Q4;
+  f32x4 psc = (f32x4){1.f, 1.f, 1.f, 1.f}, psh = (f32x4){0.f, 0.f, 0.f, 0.f}, qsc = psc, qsh = psh;
+  const float pslope = g.p_act == DVAE_ACT_LRELU ? LRELU_SLOPE : 1.f;
+  const float qslope = g.q_act == DVAE_ACT_LRELU ? LRELU_SLOPE : 1.f;
+  if (XP && g.p_scale) {
+    psc = ldg4(g.p_scale + 4 * lp4);
+    psh = ldg4(g.p_shift + 4 * lp4);
+  }
+  if (XQ && g.q_scale) {
+    qsc = ldg4(g.q_scale + 4 * lq4);
+    qsh = ldg4(g.q_shift + 4 * lq4);
+  }
+  f32x4 acc[4][NCB];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int64_t frames = g.Mtot >> 4;
+  const int64_t per = (frames + nsplit - 1) / nsplit;
+  const int64_t n0 = z * per;
+  const int64_t n1 = n0 + per < frames ? n0 + per : frames;
+
+  auto transform = [](f32x4 v, const f32x4& sc, const f32x4& sh, float slope) {
+    const f32x4 zz = v * sc + sh;         // slope <= 1: lrelu(z) = max(z, slope z)
+    const f32x4 zs = zz * slope;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(zz[e], zs[e]);
+    return v;
+  };
+  // this thread's two Q pieces: pixel (a, b) of the 4x4 grid -> Q pixel (2a-1+dh, 2b-1+dw) of the 8x8 frame
+  int qoff[2];
+  bool qin[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pi = (threadIdx.x + 256 * j) / Q4, a = pi >> 2, b = pi & 3;
+    const int hi = 2 * a - 1 + dh, wi = 2 * b - 1 + dw;
+    qin[j] = hi >= 0 && hi < 8 && wi >= 0 && wi < 8;
+    qoff[j] = qin[j] ? (hi * 8 + wi) * C2 + 4 * lq4 : 0;
+  }
+  struct Raw {
+    f32x4 p[4], q[2];
+  };
+  auto fetch = [&](int64_t n, Raw& raw) {
+    const int64_t nn = n < n1 ? n : n0;
+    const float* ps = g.P + nn * (16 * C1);
+    const float* qs = g.Q + nn * (64 * C2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) raw.p[j] = ldg4(ps + 4 * (threadIdx.x + 256 * j));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) raw.q[j] = ldg4(qs + qoff[j]);
+  };
+  auto deposit = [&](int64_t n, const Raw& raw) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 pv = XP ? transform(raw.p[j], psc, psh, pslope) : raw.p[j];
+      *reinterpret_cast<f32x4*>(&pbuf[n & 1][((threadIdx.x + 256 * j) / P4) * PSP + 4 * lp4]) = pv;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x4 qv = XQ ? transform(raw.q[j], qsc, qsh, qslope) : raw.q[j];
+      qv = zero_unless(qv, qin[j]);
+      *reinterpret_cast<f32x4*>(&qbuf[n & 1][((threadIdx.x + 256 * j) / Q4) * PSQ + 4 * lq4]) = qv;
+    }
+  };
+  Raw raw;
+  if (n0 < n1) {
+    fetch(n0, raw);
+    deposit(n0, raw);
+  }
+  __syncthreads();
+  for (int64_t n = n0; n < n1; ++n) {
+    fetch(n + 1, raw);
+    const float* pp = pbuf[n & 1];
+    const float* qq = qbuf[n & 1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pos = 4 * kq + e;                 // this lane's pixel of the K group
+      float av[4], bv[NCB];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) av[r] = pp[pos * PSP + 16 * (4 * wave + r) + i16];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) bv[cb] = qq[pos * PSQ + 16 * cb + i16];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[r][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[cb], acc[r][cb], 0, 0, 0);
+    }
+    if (n + 1 < n1) deposit(n + 1, raw);      // the other buffer: nobody reads it during this step
+    __syncthreads();
+  }
+  // D: row = c1 16(4 wave + r) + 4kq + e, column = c2 16cb + i16 of this workgroup's tap
+  float* slab = g.slab + (int64_t)z * C1 * g.NC;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        slab[(int64_t)(16 * (4 * wave + r) + 4 * kq + e) * g.NC + tap * C2 + 16 * cb + i16] = acc[r][cb][e];
+}
+
 struct WgradPlan {
-  int bm;       // 32, 64 or 128; 0 = single-channel streaming kernel; -1 / -2 = row-ring kernels
+  int bm;       // 32, 64 or 128; 0 = single-channel streaming kernel; -1 / -2 / -3 = row-ring kernels
   int64_t tm, tn;
   int split, ktiles_per_split;
 };
@@ -1909,8 +2030,16 @@ static bool wgrad_rows_shape(int64_t C1, int64_t C2, int64_t Ws) {
   return ((C1 == 64 && C2 == 32) || (C1 == 32 && C2 == 16)) && (Ws == 16 || Ws == 32);
 }
 
-static WgradPlan wgrad_plan(int64_t Mtot, int64_t Ws, int64_t C1, int64_t C2) {
+static WgradPlan wgrad_plan(int64_t Mtot, int64_t Ws, int64_t C1, int64_t C2, int64_t Hs = 0) {
   WgradPlan p;
+  if (C1 == 256 && C2 == 128 && Ws == 4 && Hs == 4 && Mtot >= 16 * 32 && dvae_mfma_precision() == DVAE_PRECISION_F32) {
+    // sixteen workgroups (filter taps) per slab; 16 x 32 = two workgroups per compute unit
+    p.bm = -3;
+    p.tm = p.tn = 1;
+    p.split = 32;
+    p.ktiles_per_split = 0;
+    return p;
+  }
   if (C2 == 1 && C1 <= 16 * WG1_MAX_CB) {
     p.bm = 0;
     p.tm = p.tn = 1;
@@ -1954,7 +2083,7 @@ static WgradPlan wgrad_plan(int64_t Mtot, int64_t Ws, int64_t C1, int64_t C2) {
 }
 
 extern "C" int64_t dvae_conv_wgrad_ws_floats(int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2) {
-  const WgradPlan p = wgrad_plan(N * Hs * Ws, Ws, C1, C2);
+  const WgradPlan p = wgrad_plan(N * Hs * Ws, Ws, C1, C2, Hs);
   // the slabs, then the partial sums of a two-stage reduction
   const int runs = wgrad_reduce_runs(p.split, C1 * C2 * 16);
   return ((int64_t)p.split + (runs > 1 ? runs : 0)) * C1 * C2 * 16;
@@ -1978,10 +2107,19 @@ extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, cons
   g.Q = Q; g.q_scale = q_scale; g.q_shift = q_shift; g.q_act = q_act;
   g.slab = ws; g.Mtot = N * Hs * Ws; g.Hs = (int)Hs; g.Ws = (int)Ws; g.lh = ilog2(Hs); g.lw = ilog2(Ws);
   g.C1 = (int)C1; g.C2 = (int)C2; g.NC = (int)(16 * C2);
-  const WgradPlan p = wgrad_plan(g.Mtot, Ws, C1, C2);
+  const WgradPlan p = wgrad_plan(g.Mtot, Ws, C1, C2, Hs);
   g.ktiles_per_split = p.ktiles_per_split;
   hipStream_t s = ST(stream);
-  if (p.bm == -2) {
+  if (p.bm == -3) {
+    DVAE_REQUIRE((!p_scale || (aligned16(p_scale) && aligned16(p_shift))) && (!q_scale || (aligned16(q_scale) && aligned16(q_shift))),
+                 "conv4s2_wgrad: scale/shift vectors must be 16-byte aligned");
+    const dim3 grid((unsigned)p.split * 16);
+    const bool xp = p_scale != nullptr || p_act != DVAE_ACT_NONE, xq = q_scale != nullptr || q_act != DVAE_ACT_NONE;
+    if (xp && xq) hipLaunchKernelGGL((wgrad_img4_kernel<true, true>), grid, dim3(256), 0, s, g);
+    else if (xp) hipLaunchKernelGGL((wgrad_img4_kernel<true, false>), grid, dim3(256), 0, s, g);
+    else if (xq) hipLaunchKernelGGL((wgrad_img4_kernel<false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((wgrad_img4_kernel<false, false>), grid, dim3(256), 0, s, g);
+  } else if (p.bm == -2) {
     DVAE_REQUIRE(Hs >= 2, "conv4s2_wgrad: Hs must be at least 2 at this shape");
     DVAE_REQUIRE((!p_scale || (aligned16(p_scale) && aligned16(p_shift))) && (!q_scale || (aligned16(q_scale) && aligned16(q_shift))),
                  "conv4s2_wgrad: scale/shift vectors must be 16-byte aligned");

@@ -265,7 +265,9 @@ WGRAD_CASES = [(3, 32, 16, 1), (4, 16, 32, 16), (3, 8, 64, 32), (2, 4, 128, 64),
                (40, 16, 16, 8), (3, 2, 256, 128), (3, 16, 64, 32), (2, 32, 32, 16), (2, 32, 64, 32), (300, 16, 64, 32),
                (70, 16, 32, 16),
                # 128 x 64 on 8-wide P: one filter row per workgroup, pairs of rows
-               (3, 8, 128, 64), (40, 8, 128, 64)]
+               (3, 8, 128, 64), (40, 8, 128, 64),
+               # 256 x 128 on 4x4 P with at least 32 frames: one filter tap per workgroup, a frame per step
+               (40, 4, 256, 128), (67, 4, 256, 128)]
 
 
 @pytest.mark.parametrize('N,Hs,C1,C2', WGRAD_CASES)
@@ -285,7 +287,7 @@ def test_conv4s2_wgrad(ops, N, Hs, C1, C2):
     assert rel_err(got, dw) < 5e-6
 
 
-@pytest.mark.parametrize('N,H,Cin,Cout', [(3, 8, 16, 8), (3, 16, 64, 32), (2, 16, 32, 16), (5, 8, 128, 64)])
+@pytest.mark.parametrize('N,H,Cin,Cout', [(3, 8, 16, 8), (3, 16, 64, 32), (2, 16, 32, 16), (5, 8, 128, 64), (40, 4, 256, 128)])
 def test_wgrad_for_transposed_conv(ops, N, H, Cin, Cout):
     # ConvTranspose2d weight gradient: P = layer input (with load transform), Q = dY
     x = rnd(N, Cin, H, H, seed=35)

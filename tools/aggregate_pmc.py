@@ -31,6 +31,8 @@ def bench_label(name):
     m = re.match(r'void deconv_rows8_kernel<(\d+), \d+, (true|false), (true|false)>', name)
     if m:
         return f"deconv_rows8_kernel<{m.group(1)}{',bnstat' if m.group(3) == 'true' else ''}>"
+    if name.startswith('void wgrad_img4_kernel<'):
+        return 'wgrad_img4_kernel'
     if name.startswith('void wgrad_rows8_kernel<'):
         return 'wgrad_rows8_kernel'
     m = re.match(r'void wgrad_rows_kernel<(\d+), (\d+),', name)
