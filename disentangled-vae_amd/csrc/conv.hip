@@ -520,7 +520,10 @@ __global__ void __launch_bounds__(256) conv_c1_kernel(ConvArgs g) {
 // one barrier per row.  Statistics (forward sums, or the BatchNorm-backward sums of ConvArgs::bn_y)
 // stay in registers and leave as one partial row per wave.
 #define ROWS_WMAX 32
-template <int CIN, int COUT, int WAVES_PER_EU, bool XF, bool BNS>
+// BNIN: the input is a gradient that still has to go through its own layer's BatchNorm backward
+// (x = du, in_y = that layer's raw output, dx = scale*dz + A*y + B formed on the way into LDS and
+// written to dx_out for the rows the workgroup owns), as in conv_rows_kernel.
+template <int CIN, int COUT, int WAVES_PER_EU, bool XF, bool BNS, bool BNIN>
 __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs g) {
   constexpr int NU = CIN / 16, NCB = COUT / 16;
   constexpr int PS = CIN + 4;                       // pixel stride in LDS: 16-byte reads without bank conflicts
@@ -547,9 +550,14 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
   const int lc4 = threadIdx.x % C4;
   f32x4 sc = (f32x4){1.f, 1.f, 1.f, 1.f}, sh = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float slope = g.in_act == DVAE_ACT_LRELU ? LRELU_SLOPE : 1.f;
-  if (XF && g.in_scale) {
+  if ((XF || BNIN) && g.in_scale) {
     sc = ldg4(g.in_scale + 4 * lc4);
     sh = ldg4(g.in_shift + 4 * lc4);
+  }
+  f32x4 ca = sh, cb2 = sh;
+  if (BNIN) {
+    ca = ldg4(g.in_a + 4 * lc4);
+    cb2 = ldg4(g.in_b + 4 * lc4);
   }
   const int row_pieces = W * C4;
   f32x4 bsc[NCB], bsh[NCB], bmu[NCB], bis[NCB];
@@ -580,24 +588,36 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
   const int64_t r0 = (int)blockIdx.x < g.mtiles ? blockIdx.x * per : rows;
   const int64_t r1 = r0 + per < rows ? r0 + per : rows;
 
-  f32x4 raw[NLD];
+  f32x4 raw[NLD], rawy[BNIN ? NLD : 1];
   auto fetch = [&](int64_t row) {            // issue the loads of a row (nothing if it does not exist)
     const bool rok = row >= 0 && row < rows;
-    const float* src = g.x + (rok ? row : 0) * (int64_t)row_pieces * 4;
+    const int64_t off = (rok ? row : 0) * (int64_t)row_pieces * 4;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int f = threadIdx.x + 256 * j;
-      raw[j] = ldg4(src + 4 * (rok && f < row_pieces ? f : 0));
+      const int64_t o = off + 4 * (rok && f < row_pieces ? f : 0);
+      raw[j] = ldg4(g.x + o);
+      if (BNIN) rawy[j] = ldg4(g.in_y + o);
     }
   };
   auto deposit = [&](int64_t row) {          // transform and write the fetched row into its slot
     float* dst = ring[row & 3];
+    const bool owned = BNIN && row >= r0 && row < r1;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int f = threadIdx.x + 256 * j;
       if (f < row_pieces) {
         f32x4 v = raw[j];
-        if (XF) {
+        if (BNIN) {
+          const f32x4 y = rawy[j];
+          const f32x4 z = y * sc + sh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dz = z[e] > 0.f ? v[e] : v[e] * LRELU_SLOPE;
+            v[e] = fmaf(sc[e], dz, fmaf(ca[e], y[e], cb2[e]));
+          }
+          if (owned) *reinterpret_cast<f32x4*>(g.dx_out + row * (int64_t)row_pieces * 4 + 4 * f) = v;
+        } else if (XF) {
           const f32x4 z = v * sc + sh;       // slope <= 1: lrelu(z) = max(z, slope z)
           const f32x4 zs = z * slope;
 #pragma unroll
@@ -1096,14 +1116,19 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     const dim3 grid((unsigned)(conv_parts_written(g.M, phases) / phases));                                \
     g.mtiles = (int)grid.x < 256 * RESIDENT ? (int)grid.x : 256 * RESIDENT;                               \
     const bool xf = g.in_scale != nullptr || g.in_act != DVAE_ACT_NONE;                                   \
-    if (bns && xf)                                                                                        \
-      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, true, true>), grid, dim3(256), 0, stream, g);   \
+    if (g.in_y != nullptr && bns)                                                                         \
+      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, false, true, true>), grid, dim3(256), 0, stream, g); \
+    else if (g.in_y != nullptr) {                                                                         \
+      dvae_set_error("%s: a BatchNorm-backward input needs the fused statistics of the layer below", name); \
+      return -EINVAL;                                                                                     \
+    } else if (bns && xf)                                                                                 \
+      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, true, true, false>), grid, dim3(256), 0, stream, g); \
     else if (bns)                                                                                         \
-      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, false, true>), grid, dim3(256), 0, stream, g);  \
+      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, false, true, false>), grid, dim3(256), 0, stream, g); \
     else if (xf)                                                                                          \
-      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, true, false>), grid, dim3(256), 0, stream, g);  \
+      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, true, false, false>), grid, dim3(256), 0, stream, g); \
     else                                                                                                  \
-      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, false, false>), grid, dim3(256), 0, stream, g); \
+      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, false, false, false>), grid, dim3(256), 0, stream, g); \
     DVAE_LAUNCH_CHECK(name);                                                                              \
     return 0;                                                                                             \
   }
@@ -1112,6 +1137,10 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   ROWS_LAUNCH(32, 16, 2, 4)
   ROWS_LAUNCH(64, 32, 2, 2)
 #undef ROWS_LAUNCH
+  if (MODE == 1 && g.in_y != nullptr) {
+    dvae_set_error("%s: no kernel takes a BatchNorm-backward input at this shape (see dvae_deconv4s2_bnin_supported)", name);
+    return -EINVAL;
+  }
   if (MODE == 1 && g.Cin == 128 && g.Cout == 64 && g.W == 8 && g.H >= 2 && aligned16(g.y) &&
       (!bns || aligned16(g.bn_y)) && (!g.in_scale || (aligned16(g.in_scale) && aligned16(g.in_shift)))) {
     const unsigned gx = (unsigned)(conv_parts_written(g.M, phases) / phases);
@@ -1236,7 +1265,8 @@ static int conv4s2_fwd_impl(const char* name, const float* x, const float* in_sc
 
 static int deconv4s2_fwd_impl(const char* name, const float* x, const float* in_scale, const float* in_shift,
                               int in_act, const float* wp, float* y, float* stat_partials, int64_t N, int64_t H,
-                              int64_t W, int64_t Cin, int64_t Cout, const BnBwdStat& bn, hipStream_t stream) {
+                              int64_t W, int64_t Cin, int64_t Cout, const BnBwdStat& bn, hipStream_t stream,
+                              const BnBwdInput& bi = BnBwdInput{nullptr, nullptr, nullptr, nullptr}) {
   DVAE_REQUIRE(N > 0 && Cout > 0, "%s: empty", name);
   DVAE_REQUIRE(is_pow2(H) && is_pow2(W), "%s: H and W must be powers of two (H=%ld W=%ld)", name, (long)H, (long)W);
   DVAE_REQUIRE(Cin % 4 == 0, "%s: Cin must be a multiple of 4 (Cin=%ld)", name, (long)Cin);
@@ -1252,7 +1282,10 @@ static int deconv4s2_fwd_impl(const char* name, const float* x, const float* in_
   g.cin32 = Cin % 32 == 0;
   g.bn_y = bn.y; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_invstd = bn.invstd;
   g.round_bf16 = dvae_mfma_precision() == DVAE_PRECISION_BF16;
-  g.in_y = nullptr; g.in_a = nullptr; g.in_b = nullptr; g.dx_out = nullptr;
+  g.in_y = bi.y; g.in_a = bi.a; g.in_b = bi.b; g.dx_out = bi.dx_out;
+  DVAE_REQUIRE(bi.y == nullptr || (in_scale && in_shift && bi.a && bi.b && bi.dx_out && aligned16(bi.y) &&
+                                   aligned16(bi.a) && aligned16(bi.b) && aligned16(bi.dx_out)),
+               "%s: a BatchNorm-backward input needs y, scale, shift, A, B and dx_out, 16-byte aligned", name);
   return launch_conv_fwd<1>(name, g, 4, stream);
 }
 
@@ -1306,6 +1339,25 @@ extern "C" int dvae_deconv4s2_dgrad_bnstat_f32(const float* x, const float* wp, 
                             W, Cin, Cout, BnBwdStat{bn_y, bn_scale, bn_shift, bn_mean, bn_invstd}, ST(stream));
 }
 
+extern "C" int dvae_deconv4s2_bnin_supported(int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
+  (void)H;
+  return dvae_mfma_precision() == DVAE_PRECISION_F32 && Cin == 32 && Cout == 16 && (W == 16 || W == 32);
+}
+
+extern "C" int dvae_deconv4s2_dgrad_bnstat_bnin_f32(const float* du_in, const float* in_y, const float* in_scale,
+                                                    const float* in_shift, const float* in_a, const float* in_b,
+                                                    float* dx_out, const float* wp, float* y, float* stat_partials,
+                                                    int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                                                    const float* bn_y, const float* bn_scale, const float* bn_shift,
+                                                    const float* bn_mean, const float* bn_invstd,
+                                                    dvae_stream_t stream) {
+  DVAE_REQUIRE(bn_y != nullptr && in_y != nullptr, "deconv4s2_dgrad_bnstat_bnin: bn_y / in_y is null");
+  DVAE_REQUIRE(dvae_deconv4s2_bnin_supported(H, W, Cin, Cout), "deconv4s2_dgrad_bnstat_bnin: unsupported shape or precision");
+  return deconv4s2_fwd_impl("deconv4s2_dgrad_bnstat_bnin", du_in, in_scale, in_shift, DVAE_ACT_NONE, wp, y, stat_partials,
+                            N, H, W, Cin, Cout, BnBwdStat{bn_y, bn_scale, bn_shift, bn_mean, bn_invstd}, ST(stream),
+                            BnBwdInput{in_y, in_a, in_b, dx_out});
+}
+
 // Host helper used by the Python side through dvae_conv_stat_parts is an upper bound; the exact
 // number of rows written is needed by bn_finalize, so expose it.
 extern "C" int64_t dvae_conv_stat_parts_written(int64_t M_rows_per_phase, int phases) {
@@ -1328,6 +1380,11 @@ struct WgradArgs {
   int Hs, Ws, lh, lw;
   int C1, C2, NC;  // NC = 16*C2
   int ktiles_per_split;
+  // P not yet through its BatchNorm backward (single-channel-Q kernel only): P is du, p_y the layer's
+  // raw output, p_scale/p_shift its forward affine, and P becomes scale*dz + A*y + B as it is loaded
+  const float* p_y;
+  const float* p_a;
+  const float* p_b;
 };
 
 // Both operands of the weight-gradient GEMM are row-contiguous tiles whose column position is
@@ -1473,7 +1530,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs g) {
 // from the single-channel image), accumulates [channels][taps] in registers over its whole pixel
 // range and the four waves' partials are summed through LDS once at the end.
 #define WG1_MAX_CB 8   // up to 128 channels
-template <int NCB, int U>
+template <int NCB, int U, bool BNP>
 __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(WgradArgs g) {
   __shared__ float red[4 * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1484,19 +1541,21 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(WgradArgs g) {
   f32x4 acc[NCB];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float psc[NCB], psh[NCB];
+  float psc[NCB], psh[NCB], pca[NCB], pcb[NCB];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
     const int c = cb * 16 + i16;
     const bool ok = cb < ncb && c < g.C1 && g.p_scale != nullptr;
     psc[cb] = ok ? g.p_scale[c] : 1.f;
     psh[cb] = ok ? g.p_shift[c] : 0.f;
+    pca[cb] = BNP && ok ? g.p_a[c] : 0.f;
+    pcb[cb] = BNP && ok ? g.p_b[c] : 0.f;
   }
   const int64_t nblk = (g.Mtot + 3) / 4;        // blocks of 4 pixels
   const int64_t wid = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
   // U pixel blocks per iteration: all their loads are issued before the first MFMA
   for (int64_t blk = wid; blk < nblk; blk += U * nw) {
-    float qv[U], pv[U][NCB];
+    float qv[U], pv[U][NCB], yv[U][BNP ? NCB : 1];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t m = (blk + u * nw) * 4 + kq;
@@ -1514,7 +1573,10 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(WgradArgs g) {
         pv[u][cb] = 0.f;
         if (cb < ncb) {
           const int c = cb * 16 + i16;
-          if (mok && c < g.C1) pv[u][cb] = g.P[m * g.C1 + c];
+          if (mok && c < g.C1) {
+            pv[u][cb] = g.P[m * g.C1 + c];
+            if (BNP) yv[u][cb] = g.p_y[m * g.C1 + c];
+          }
         }
       }
     }
@@ -1527,8 +1589,14 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(WgradArgs g) {
         if (cb < ncb) {
           float v = pv[u][cb];
           if (mok && cb * 16 + i16 < g.C1) {
-            if (g.p_scale) v = fmaf(v, psc[cb], psh[cb]);
-            if (g.p_act == DVAE_ACT_LRELU) v = lrelu(v);
+            if (BNP) {
+              const float y = yv[u][cb], zz = fmaf(y, psc[cb], psh[cb]);
+              const float dz = zz > 0.f ? v : v * LRELU_SLOPE;
+              v = fmaf(psc[cb], dz, fmaf(pca[cb], y, pcb[cb]));
+            } else {
+              if (g.p_scale) v = fmaf(v, psc[cb], psh[cb]);
+              if (g.p_act == DVAE_ACT_LRELU) v = lrelu(v);
+            }
           } else {
             v = 0.f;
           }
@@ -2089,10 +2157,10 @@ extern "C" int64_t dvae_conv_wgrad_ws_floats(int64_t N, int64_t Hs, int64_t Ws, 
   return ((int64_t)p.split + (runs > 1 ? runs : 0)) * C1 * C2 * 16;
 }
 
-extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, const float* p_shift, int p_act,
-                                      const float* Q, const float* q_scale, const float* q_shift, int q_act,
-                                      float* dw, float* ws, int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2,
-                                      dvae_stream_t stream) {
+static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float* p_shift, int p_act,
+                              const float* Q, const float* q_scale, const float* q_shift, int q_act,
+                              float* dw, float* ws, int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2,
+                              const float* p_y, const float* p_a, const float* p_b, dvae_stream_t stream) {
   DVAE_REQUIRE(N > 0 && C1 > 0 && C2 > 0, "conv4s2_wgrad: empty");
   DVAE_REQUIRE(is_pow2(Hs) && is_pow2(Ws), "conv4s2_wgrad: Hs and Ws must be powers of two");
   DVAE_REQUIRE(C1 % 4 == 0, "conv4s2_wgrad: C1 must be a multiple of 4 (C1=%ld)", (long)C1);
@@ -2107,6 +2175,9 @@ extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, cons
   g.Q = Q; g.q_scale = q_scale; g.q_shift = q_shift; g.q_act = q_act;
   g.slab = ws; g.Mtot = N * Hs * Ws; g.Hs = (int)Hs; g.Ws = (int)Ws; g.lh = ilog2(Hs); g.lw = ilog2(Ws);
   g.C1 = (int)C1; g.C2 = (int)C2; g.NC = (int)(16 * C2);
+  g.p_y = p_y; g.p_a = p_a; g.p_b = p_b;
+  DVAE_REQUIRE(p_y == nullptr || (C2 == 1 && p_scale && p_shift && p_a && p_b),
+               "conv4s2_wgrad: a BatchNorm-backward P needs a single-channel Q and scale, shift, A, B");
   const WgradPlan p = wgrad_plan(g.Mtot, Ws, C1, C2, Hs);
   g.ktiles_per_split = p.ktiles_per_split;
   hipStream_t s = ST(stream);
@@ -2147,10 +2218,15 @@ extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, cons
   } else if (p.bm == 0) {
     const int ncb = (int)((C1 + 15) / 16);
     const dim3 grid((unsigned)p.split);
-    if (ncb <= 1) hipLaunchKernelGGL((conv_wgrad_c1_kernel<1, 8>), grid, dim3(256), 0, s, g);
-    else if (ncb <= 2) hipLaunchKernelGGL((conv_wgrad_c1_kernel<2, 8>), grid, dim3(256), 0, s, g);
-    else if (ncb <= 4) hipLaunchKernelGGL((conv_wgrad_c1_kernel<4, 4>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((conv_wgrad_c1_kernel<8, 2>), grid, dim3(256), 0, s, g);
+    if (g.p_y != nullptr) {
+      if (ncb <= 1) hipLaunchKernelGGL((conv_wgrad_c1_kernel<1, 8, true>), grid, dim3(256), 0, s, g);
+      else if (ncb <= 2) hipLaunchKernelGGL((conv_wgrad_c1_kernel<2, 4, true>), grid, dim3(256), 0, s, g);
+      else if (ncb <= 4) hipLaunchKernelGGL((conv_wgrad_c1_kernel<4, 2, true>), grid, dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((conv_wgrad_c1_kernel<8, 1, true>), grid, dim3(256), 0, s, g);
+    } else if (ncb <= 1) hipLaunchKernelGGL((conv_wgrad_c1_kernel<1, 8, false>), grid, dim3(256), 0, s, g);
+    else if (ncb <= 2) hipLaunchKernelGGL((conv_wgrad_c1_kernel<2, 8, false>), grid, dim3(256), 0, s, g);
+    else if (ncb <= 4) hipLaunchKernelGGL((conv_wgrad_c1_kernel<4, 4, false>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((conv_wgrad_c1_kernel<8, 2, false>), grid, dim3(256), 0, s, g);
   } else {
     const dim3 grid((unsigned)p.tn, (unsigned)p.tm, (unsigned)p.split);
     const bool bf = dvae_mfma_precision() == DVAE_PRECISION_BF16;
@@ -2186,6 +2262,22 @@ extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, cons
   }
   DVAE_LAUNCH_CHECK("conv4s2_wgrad_reduce");
   return 0;
+}
+
+extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, const float* p_shift, int p_act,
+                                      const float* Q, const float* q_scale, const float* q_shift, int q_act,
+                                      float* dw, float* ws, int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2,
+                                      dvae_stream_t stream) {
+  return conv4s2_wgrad_impl(P, p_scale, p_shift, p_act, Q, q_scale, q_shift, q_act, dw, ws, N, Hs, Ws, C1, C2, nullptr,
+                            nullptr, nullptr, stream);
+}
+
+extern "C" int dvae_conv4s2_wgrad_bnp_f32(const float* du, const float* p_y, const float* p_scale, const float* p_shift,
+                                          const float* p_a, const float* p_b, const float* Q, float* dw, float* ws,
+                                          int64_t N, int64_t Hs, int64_t Ws, int64_t C1, dvae_stream_t stream) {
+  DVAE_REQUIRE(p_y != nullptr, "conv4s2_wgrad_bnp: p_y is null");
+  return conv4s2_wgrad_impl(du, p_scale, p_shift, DVAE_ACT_NONE, Q, nullptr, nullptr, DVAE_ACT_NONE, dw, ws, N, Hs, Ws,
+                            C1, 1, p_y, p_a, p_b, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

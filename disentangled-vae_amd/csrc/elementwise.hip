@@ -829,6 +829,20 @@ extern "C" int dvae_bn_bwd_f32(float* du, const float* y, const float* scale, co
   return 0;
 }
 
+// step 1 alone: the partial rows [rows][2][C] of (sum dz, sum dz*xhat), for dvae_bn_bwd_coeffs_f32
+extern "C" int64_t dvae_bn_bwd_reduce_rows(int64_t M, int64_t C) { return colsum_geom(M, C).gx; }
+
+extern "C" int dvae_bn_bwd_reduce_f32(const float* du, const float* y, const float* scale, const float* shift,
+                                      const float* mean, const float* invstd, float* partials, int64_t M, int64_t C,
+                                      dvae_stream_t stream) {
+  DVAE_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd_reduce: need C%%4==0 (C=%ld)", (long)C);
+  const ColsumGeom g = colsum_geom(M, C);
+  hipLaunchKernelGGL(colsum_kernel<0>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), const_cast<float*>(du), y,
+                     scale, shift, mean, invstd, 0, partials, M, C, g.tx, g.ty);
+  DVAE_LAUNCH_CHECK("bn_bwd_reduce");
+  return 0;
+}
+
 extern "C" int dvae_bn_bwd_from_partials_f32(float* du, const float* y, const float* scale, const float* shift,
                                              const float* mean, const float* invstd, const float* partials,
                                              int64_t nparts, float* dgamma, float* dbeta, int64_t M, int64_t C,

@@ -67,6 +67,11 @@ SIGNATURES = {
     'dvae_deconv4s2_dgrad_bnstat_f32': (I, [P, P, P, P, L, L, L, L, L, P, P, P, P, P, P]),
     'dvae_bn_bwd_from_partials_f32': (I, [P, P, P, P, P, P, P, L, P, P, L, L, P]),
     'dvae_bn_bwd_coeffs_f32': (I, [P, L, P, P, P, P, P, P, P, L, L, P]),
+    'dvae_bn_bwd_reduce_rows': (L, [L, L]),
+    'dvae_bn_bwd_reduce_f32': (I, [P, P, P, P, P, P, P, L, L, P]),
+    'dvae_deconv4s2_bnin_supported': (I, [L, L, L, L]),
+    'dvae_deconv4s2_dgrad_bnstat_bnin_f32': (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P, P, P, P, P, P]),
+    'dvae_conv4s2_wgrad_bnp_f32': (I, [P, P, P, P, P, P, P, P, P, L, L, L, L, P]),
     'dvae_conv4s2_bnin_supported': (I, [L, L, L, L]),
     'dvae_conv4s2_dgrad_bnstat_bnin_f32': (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P, P, P, P, P, P]),
     'dvae_conv_wgrad_ws_floats': (L, [L, L, L, L, L]),

@@ -113,6 +113,25 @@ class EncoderCNN(torch.autograd.Function):
         parts = None                      # BatchNorm-backward statistics reduced by the producer of du
         for l in range(L - 1, -1, -1):
             sc, sh, mean, invstd = affs[l]
+            M = du.numel() // du.shape[-1]
+            # Where the consumer of dL/dy can form it from (du, y) as it loads them, the elementwise
+            # BatchNorm-backward pass is skipped: only the batch sums and two coefficient vectors are made.
+            if l == 0 and x.shape[-1] == 1 and du.shape[-1] <= 128:
+                if parts is None:
+                    parts = ops.bn_bwd_reduce(du, ys[0], affs[0])
+                d_gamma[0], d_beta[0], ca, cb = ops.bn_bwd_coeffs(parts, affs[0], M)
+                d_conv[0] = ops.conv4s2_wgrad_bnp(du, ys[0], affs[0], ca, cb, x)
+                continue
+            if (l > 0 and _fuse_bn_stats(ys[l - 1].shape[-1])
+                    and ops.deconv4s2_bnin_supported(du, conv_w[l].shape[1])):
+                if parts is None:
+                    parts = ops.bn_bwd_reduce(du, ys[l], affs[l])
+                d_gamma[l], d_beta[l], ca, cb = ops.bn_bwd_coeffs(parts, affs[l], M)
+                wpd = ops.pack_deconv_w(conv_w[l])
+                du, parts, dy = ops.deconv4s2_dgrad_bnstat_bnin(du, ys[l], affs[l], ca, cb, wpd, ys[l - 1], affs[l - 1])
+                psc, psh = affs[l - 1][0], affs[l - 1][1]
+                d_conv[l] = ops.conv4s2_wgrad(dy, None, None, ops.ACT_NONE, ys[l - 1], psc, psh, ops.ACT_LRELU)
+                continue
             d_gamma[l], d_beta[l] = ops.bn_bwd(du, ys[l], sc, sh, mean, invstd, ctx.gammas[l], parts)
             dy = du                                              # now dL/d(raw conv output)
             if l > 0:

@@ -394,6 +394,56 @@ def bn_bwd_coeffs(partials: Tensor, aff, M: int):
     return out[0], out[1], out[2], out[3]
 
 
+def bn_bwd_reduce(du: Tensor, y: Tensor, aff) -> Tensor:
+    """The BatchNorm-backward sums alone: partial rows [rows][2][C] for bn_bwd_coeffs."""
+    sc, sh, mean, invstd = aff
+    _chk(du, y, sc, sh, mean, invstd)
+    C = y.shape[-1]
+    M = y.numel() // C
+    parts = torch.empty(lib.dvae_bn_bwd_reduce_rows(M, C), 2, C, dtype=torch.float32, device=y.device)
+    check(lib.dvae_bn_bwd_reduce_f32(_p(du), _p(y), _p(sc), _p(sh), _p(mean), _p(invstd), _p(parts), M, C, _stream()),
+          'bn_bwd_reduce')
+    return parts
+
+
+def deconv4s2_bnin_supported(x: Tensor, Cout: int) -> bool:
+    N, H, W, Cin = x.shape
+    return bool(lib.dvae_deconv4s2_bnin_supported(H, W, Cin, Cout))
+
+
+def deconv4s2_dgrad_bnstat_bnin(du_in: Tensor, in_y: Tensor, in_aff, coef_a: Tensor, coef_b: Tensor, wp: Tensor,
+                                bn_y: Tensor, bn_aff):
+    """deconv4s2_dgrad_bnstat on an input that still needs its own BatchNorm backward (see
+    conv4s2_dgrad_bnstat_bnin); returns (du, partials, dx)."""
+    _chk(du_in, in_y, wp, bn_y, coef_a, coef_b, *in_aff, *bn_aff)
+    assert du_in.shape == in_y.shape
+    N, H, W, Cin = du_in.shape
+    Cout = wp.shape[1]
+    y = torch.empty(N, 2 * H, 2 * W, Cout, dtype=torch.float32, device=du_in.device)
+    assert bn_y.shape == y.shape
+    dx = torch.empty_like(du_in)
+    nparts = lib.dvae_conv_stat_parts_written(N * H * W, 4)
+    stats = torch.empty(nparts, 2, Cout, dtype=torch.float32, device=du_in.device)
+    sc, sh, mean, invstd = bn_aff
+    check(lib.dvae_deconv4s2_dgrad_bnstat_bnin_f32(_p(du_in), _p(in_y), _p(in_aff[0]), _p(in_aff[1]), _p(coef_a),
+                                                   _p(coef_b), _p(dx), _p(wp), _p(y), _p(stats), N, H, W, Cin, Cout,
+                                                   _p(bn_y), _p(sc), _p(sh), _p(mean), _p(invstd), _stream()),
+          'deconv4s2_dgrad_bnstat_bnin')
+    return y, stats, dx
+
+
+def conv4s2_wgrad_bnp(du: Tensor, p_y: Tensor, p_aff, coef_a: Tensor, coef_b: Tensor, Q: Tensor) -> Tensor:
+    """conv4s2_wgrad with a single-channel Q whose P = du still needs its layer's BatchNorm backward."""
+    _chk(du, p_y, Q, coef_a, coef_b, *p_aff)
+    N, Hs, Ws, C1 = du.shape
+    assert du.shape == p_y.shape and Q.shape == (N, 2 * Hs, 2 * Ws, 1)
+    dw = torch.empty(C1, 1, 4, 4, dtype=torch.float32, device=du.device)
+    ws = workspace(lib.dvae_conv_wgrad_ws_floats(N, Hs, Ws, C1, 1), du.device)
+    check(lib.dvae_conv4s2_wgrad_bnp_f32(_p(du), _p(p_y), _p(p_aff[0]), _p(p_aff[1]), _p(coef_a), _p(coef_b), _p(Q),
+                                         _p(dw), _p(ws), N, Hs, Ws, C1, _stream()), 'conv4s2_wgrad_bnp')
+    return dw
+
+
 def conv4s2_bnin_supported(x: Tensor, Cout: int) -> bool:
     N, H, W, Cin = x.shape
     return bool(lib.dvae_conv4s2_bnin_supported(H, W, Cin, Cout))

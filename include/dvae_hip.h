@@ -129,6 +129,11 @@ int dvae_bn_bwd_f32(float* du, const float* y, const float* scale, const float* 
 int dvae_bn_bwd_coeffs_f32(const float* partials, int64_t nparts, const float* scale, const float* mean,
                            const float* invstd, float* dgamma, float* dbeta, float* coef_a, float* coef_b,
                            int64_t M, int64_t C, dvae_stream_t stream);
+/* Step 1 alone: partials [dvae_bn_bwd_reduce_rows(M,C)][2][C], the rows dvae_bn_bwd_coeffs_f32 takes. */
+int64_t dvae_bn_bwd_reduce_rows(int64_t M, int64_t C);
+int dvae_bn_bwd_reduce_f32(const float* du, const float* y, const float* scale, const float* shift,
+                           const float* mean, const float* invstd, float* partials, int64_t M, int64_t C,
+                           dvae_stream_t stream);
 int dvae_bn_bwd_from_partials_f32(float* du, const float* y, const float* scale, const float* shift,
                                   const float* mean, const float* invstd, const float* partials, int64_t nparts,
                                   float* dgamma, float* dbeta, int64_t M, int64_t C, dvae_stream_t stream);
@@ -216,6 +221,15 @@ int dvae_conv4s2_dgrad_bnstat_bnin_f32(const float* du_in, const float* in_y, co
                                        int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                                        const float* bn_y, const float* bn_scale, const float* bn_shift,
                                        const float* bn_mean, const float* bn_invstd, dvae_stream_t stream);
+/* The transposed-conv counterpart (the encoder's conv -> BatchNorm -> LeakyReLU blocks,
+ * models/encoders.py:32-36, walked backwards); same arguments and rules. */
+int dvae_deconv4s2_bnin_supported(int64_t H, int64_t W, int64_t Cin, int64_t Cout);
+int dvae_deconv4s2_dgrad_bnstat_bnin_f32(const float* du_in, const float* in_y, const float* in_scale,
+                                         const float* in_shift, const float* in_a, const float* in_b,
+                                         float* dx_out, const float* wp, float* y, float* stat_partials,
+                                         int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                                         const float* bn_y, const float* bn_scale, const float* bn_shift,
+                                         const float* bn_mean, const float* bn_invstd, dvae_stream_t stream);
 int dvae_deconv4s2_dgrad_bnstat_f32(const float* x, const float* wp, float* y, float* stat_partials, int64_t N,
                                     int64_t H, int64_t W, int64_t Cin, int64_t Cout, const float* bn_y,
                                     const float* bn_scale, const float* bn_shift, const float* bn_mean,
@@ -231,6 +245,14 @@ int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, const float* p_
                            const float* Q, const float* q_scale, const float* q_shift, int q_act,
                            float* dw, float* ws, int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2,
                            dvae_stream_t stream);
+/* Weight gradient of the first encoder convolution (single-channel Q = the frames, models/encoders.py:32)
+ * whose P = dL/d(activation) has not been through that layer's BatchNorm backward: du, the layer's raw
+ * output p_y, its forward affine and the vectors of dvae_bn_bwd_coeffs_f32; P becomes scale*dz + A*y + B
+ * as it is loaded, so the first layer needs no elementwise BatchNorm-backward pass at all.  ws as for
+ * dvae_conv4s2_wgrad_f32 with C2 = 1. */
+int dvae_conv4s2_wgrad_bnp_f32(const float* du, const float* p_y, const float* p_scale, const float* p_shift,
+                               const float* p_a, const float* p_b, const float* Q, float* dw, float* ws,
+                               int64_t N, int64_t Hs, int64_t Ws, int64_t C1, dvae_stream_t stream);
 /* Final decoder layer (models/decoders.py:49-53,67-68): ConvTranspose2d(Cin -> 1, bias) + sigmoid.
  * x [N,H,W,Cin] (+ load-time transform), w torch layout [Cin][1][4][4], y [N,2H,2W]. Cin%4==0. */
 int dvae_deconv4s2_final_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,

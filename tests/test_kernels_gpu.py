@@ -562,6 +562,60 @@ def test_dgrad_that_applies_the_bn_backward_of_its_input(ops, N, H):
     assert rel_err(got_parts.double().sum(0), ref_parts.double().sum(0)) < 2e-5
 
 
+def _bn_case(shape, C, seed):
+    """(du, y, gamma, aff on device, dz, xhat, sc) for a BatchNorm + LeakyReLU layer with NHWC tensors of `shape`"""
+    du, y = rnd(*shape, seed=seed), rnd(*shape, seed=seed + 1)
+    gamma, beta = 1 + 0.3 * rnd(C, seed=seed + 2), 0.2 * rnd(C, seed=seed + 3)
+    mean, var = y.mean(dim=(0, 1, 2)), y.var(dim=(0, 1, 2), unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    sc, sh = gamma * invstd, beta - mean * gamma * invstd
+    dz = du * torch.where(y * sc + sh > 0, 1.0, 0.2)
+    return du, y, gamma, (dev(sc), dev(sh), dev(mean), dev(invstd)), dz, (y - mean) * invstd, sc
+
+
+@pytest.mark.parametrize('N,H', [(3, 16), (70, 16), (5, 32)])
+def test_transposed_dgrad_that_applies_the_bn_backward_of_its_input(ops, N, H):
+    """deconv4s2_dgrad_bnstat_bnin (and bn_bwd_reduce feeding it) against bn_bwd + deconv4s2_dgrad_bnstat."""
+    Cin, Cout = 32, 16
+    du, y, gamma, aff, dz, xhat, sc = _bn_case((N, H, H, Cin), Cin, 100)
+    M = N * H * H
+    w = rnd(Cin, Cout, 4, 4, seed=104, scale=0.2)
+    wp = ops.pack_deconv_w(dev(w))
+    _, yb, _, aff_below, _, _, _ = _bn_case((N, 2 * H, 2 * H, Cout), Cout, 110)
+    assert ops.deconv4s2_bnin_supported(dev(du), Cout)
+    parts = ops.bn_bwd_reduce(dev(du), dev(y), aff)
+    assert rel_err(parts.double().sum(0)[0], dz.sum(dim=(0, 1, 2))) < 2e-5
+    assert rel_err(parts.double().sum(0)[1], (dz * xhat).sum(dim=(0, 1, 2))) < 2e-5
+    dg, db, ca, cb = ops.bn_bwd_coeffs(parts, aff, M)
+    got_du, got_parts, got_dx = ops.deconv4s2_dgrad_bnstat_bnin(dev(du), dev(y), aff, ca, cb, wp, dev(yb), aff_below)
+    ref_dx = dev(du)
+    rg, rb = ops.bn_bwd(ref_dx, dev(y), *aff, dev(gamma))
+    ref_du, ref_parts = ops.deconv4s2_dgrad_bnstat(ref_dx, wp, dev(yb), aff_below)
+    assert rel_err(dg, rg) < 1e-5 and rel_err(db, rb) < 1e-5
+    dx64 = sc * (dz - dz.sum(dim=(0, 1, 2)) / M - xhat * (dz * xhat).sum(dim=(0, 1, 2)) / M)
+    assert rel_err(got_dx, dx64) < 2e-6
+    assert rel_err(got_du, ref_du) < 2e-6
+    assert rel_err(got_parts.double().sum(0), ref_parts.double().sum(0)) < 2e-5
+
+
+@pytest.mark.parametrize('N,Hs,C1', [(3, 32, 16), (5, 32, 32), (2, 16, 64), (40, 32, 16)])
+def test_first_layer_wgrad_that_applies_the_bn_backward_of_its_gradient(ops, N, Hs, C1):
+    """conv4s2_wgrad_bnp against bn_bwd followed by conv4s2_wgrad with a single-channel Q."""
+    du, y, gamma, aff, dz, xhat, sc = _bn_case((N, Hs, Hs, C1), C1, 120)
+    M = N * Hs * Hs
+    frames = rnd(N, 2 * Hs, 2 * Hs, 1, seed=125)
+    parts = ops.bn_bwd_reduce(dev(du), dev(y), aff)
+    dg, db, ca, cb = ops.bn_bwd_coeffs(parts, aff, M)
+    got = ops.conv4s2_wgrad_bnp(dev(du), dev(y), aff, ca, cb, dev(frames))
+    ref_dx = dev(du)
+    ops.bn_bwd(ref_dx, dev(y), *aff, dev(gamma))
+    ref = ops.conv4s2_wgrad(ref_dx, None, None, ops.ACT_NONE, dev(frames), None, None, ops.ACT_NONE)
+    dx64 = sc * (dz - dz.sum(dim=(0, 1, 2)) / M - xhat * (dz * xhat).sum(dim=(0, 1, 2)) / M)
+    wz = torch.zeros(C1, 1, 4, 4, dtype=torch.float64, requires_grad=True)
+    (dw64,) = torch.autograd.grad(F.conv2d(nchw(frames), wz, None, stride=2, padding=1), wz, nchw(dx64))
+    assert rel_err(got, dw64) < 5e-6 and rel_err(ref, dw64) < 5e-6
+
+
 # ------------------------------------------------------------------ data gradient + BatchNorm-backward statistics
 @pytest.mark.parametrize('kind,N,H,Cin,Cout', [('conv', 5, 32, 16, 32), ('conv', 3, 64, 1, 16), ('conv', 3, 64, 1, 32),
                                                ('conv', 4, 32, 32, 64), ('conv', 2, 64, 32, 64),
