@@ -2391,7 +2391,7 @@ extern "C" int dvae_deconv4s2_final_fwd_f32(const float* x, const float* in_scal
   DeconvFinalArgs g;
   g.x = x; g.in_scale = in_scale; g.in_shift = in_shift; g.w = w; g.bias = bias; g.y = y;
   g.in_act = in_act; g.out_act = out_act; g.H = (int)H; g.W = (int)W; g.lw = ilog2(W); g.Cin = (int)Cin;
-  g.R = H >= 8 ? 8 : (int)H;
+  g.R = H >= 16 ? 16 : (int)H;     // rows per band: the two halo rows are read twice, so not too few
   g.bands = (int)(H / g.R);
   const size_t lds = (size_t)(g.R + 2) * W * 16 * 4;
   hipLaunchKernelGGL(deconv_final_kernel, dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);
