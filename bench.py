@@ -324,8 +324,9 @@ def main():
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group and use the data-parallel step even with one rank '
                          '(exercises the multi-GPU code path on a single GPU)')
-    ap.add_argument('--graph', type=int, default=-1, help='1: replay a captured hipGraph per step; 0: eager; '
-                    '-1: graph on one GPU, eager (overlapped all-reduce) on several')
+    ap.add_argument('--graph', type=int, default=-1, help='0: eager launches (several ranks: bucketed all-reduces '
+                    'overlapped with backward); otherwise replay the captured step (several ranks: two hipGraphs '
+                    'around one gradient all-reduce)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -360,7 +361,8 @@ def main():
     n_params = sum(p.numel() for p in model.parameters())
     opt = FusedAdam(model.parameters(), lr=t['learning_rate'], betas=(t['beta1'], t['beta2']),
                     weight_decay=t['weight_decay'])
-    sync = GradSync(model, bucket_mb=args.bucket_mb) if use_dp else None
+    use_graph_early = args.mode == 'train' and args.graph != 0
+    sync = GradSync(model, bucket_mb=args.bucket_mb) if (use_dp and not use_graph_early) else None
     ring = [synthetic_clips(B, T, size, 1000 * rank + i).to(dev) for i in range(4)]
     beta = 4.0
 
@@ -384,17 +386,18 @@ def main():
         with torch.no_grad():
             return model(ring[i % len(ring)])
 
-    use_graph = args.mode == 'train' and (args.graph == 1 or (args.graph == -1 and not use_dp))
-    if use_graph and use_dp:
-        raise SystemExit("--graph 1 is single-GPU only for now (the all-reduce is launched from autograd hooks)")
+    # default: the captured step everywhere (with several ranks: two graphs around one all-reduce);
+    # --graph 0 is the eager step (with several ranks: bucketed all-reduces overlapped with backward)
+    use_graph = args.mode == 'train' and args.graph != 0
 
     def make_train_step():
         model.train()
         if not use_graph:
             return train_step
-        from hipvae.graph import GraphedTrainStep
-        gstep = GraphedTrainStep(model, opt, lambda m, v: loss_call(kind, L, m(v), v, t, beta), ring[0],
-                                 gradient_clip=t['gradient_clip'])
+        from hipvae.graph import GraphedDataParallelStep, GraphedTrainStep
+        cls = GraphedDataParallelStep if use_dp else GraphedTrainStep
+        gstep = cls(model, opt, lambda m, v: loss_call(kind, L, m(v), v, t, beta), ring[0],
+                    gradient_clip=t['gradient_clip'])
         return lambda i: gstep(ring[i % len(ring)])
 
     def barrier():
@@ -435,7 +438,7 @@ def main():
         'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
         'config': {'workload': f"{cfg['name']} ({args.config}) {args.mode} step, beta=4, {T}x{size}x{size} clips, "
-                               f"batch {B}/GPU, {prec_label}, {'hipGraph replay' if use_graph else 'eager launches'}",
+                               f"batch {B}/GPU, {prec_label}, {('hipGraph replay' + (' (backward graph, one all-reduce, update graph)' if use_dp else '')) if use_graph else 'eager launches'}",
                    'global_batch': B * world, 'params': n_params,
                    'parallelism': f'dp{world}'},
     }

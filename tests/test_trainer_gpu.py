@@ -269,14 +269,35 @@ def test_gradsync_on_rccl_single_rank_equals_plain_step():
     s.close()
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    def run_graphed(parallel):
+        """the captured step: one graph, or the data-parallel pair of graphs around one all-reduce"""
+        from hipvae.graph import GraphedDataParallelStep, GraphedTrainStep
+        torch.manual_seed(21)
+        m = models.DisentangledVAE(**cfg).cuda().train()
+        opt = FusedAdam(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        loss_of = lambda mm, v: losses.disentangled_loss(mm(v), v, beta=0.5, recon_loss_type='bce',
+                                                         independence_weight=0.1, temporal_weight=0.05)
+        step = (GraphedDataParallelStep if parallel else GraphedTrainStep)(m, opt, loss_of, batches[0], gradient_clip=1.0)
+        if parallel:
+            assert all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(step.params, step.views))
+        for v in batches:
+            out = step(v)
+        assert torch.isfinite(out['total_loss'])
+        assert float(opt.state_dict()['state'][0]['step']) == 3.0
+        return {k: v.clone() for k, v in m.state_dict().items()}
+
     try:
         plain = run(False)
         synced = run(True)
+        graphed = run_graphed(False)
+        graphed_dp = run_graphed(True)
     finally:
         dist.destroy_process_group()
         rng.draw_like = orig
     for k in plain:
         assert torch.equal(plain[k], synced[k]), (k, (plain[k].float() - synced[k].float()).abs().max().item())
+        # one rank: the two-graph data-parallel step is the one-graph step, bit for bit
+        assert torch.equal(graphed[k], graphed_dp[k]), (k, (graphed[k].float() - graphed_dp[k].float()).abs().max().item())
 
 
 @pytest.mark.parametrize('flags', [[], ['--hip-graph', '--gpu-render'], ['--precision', 'bf16', '--gpu-render']])
