@@ -208,6 +208,22 @@ class KernelTimer:
         self._wrap('conv4s2_dgrad_bnstat', conv_bn_key)
         self._wrap('deconv4s2_dgrad_bnstat', deconv_bn_key)
         self._wrap('conv4s2_dgrad_bnstat_bnin', conv_bnin_key)
+
+        def deconv_bnin_key(du_in, in_y, in_aff, ca, cb, wp, bn_y, bn_aff):
+            key, work, unit = deconv_key(du_in, None, None, 0, wp, True)
+            return key[:-1] + ',bnstat,bnin>', work, unit
+
+        def wgrad_bnq_key(P, ps, ph, pa, du, q_y, q_aff, ca, cb):
+            key, work, unit = wgrad_key(P, ps, ph, pa, du, None, None, 0)
+            return key + ',bnq', work, unit
+
+        def wgrad_bnp_key(du, p_y, p_aff, ca, cb, Q):
+            key, work, unit = wgrad_key(du, None, None, 0, Q, None, None, 0)
+            return key[:-1] + ',bnp>', work, unit
+
+        self._wrap('deconv4s2_dgrad_bnstat_bnin', deconv_bnin_key)
+        self._wrap('conv4s2_wgrad_bnq', wgrad_bnq_key)
+        self._wrap('conv4s2_wgrad_bnp', wgrad_bnp_key)
         self._wrap('conv4s2_wgrad', wgrad_key)
         self._wrap('gemm_nt', gemm_key('nt'))
         self._wrap('gemm_nn', gemm_key('nn'))

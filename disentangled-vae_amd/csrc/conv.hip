@@ -1385,6 +1385,11 @@ struct WgradArgs {
   const float* p_y;
   const float* p_a;
   const float* p_b;
+  // the same for Q (wgrad_rows8_kernel only); the finished rows of dL/dy are also written to dx_out
+  const float* q_y;
+  const float* q_a;
+  const float* q_b;
+  float* dx_out;
 };
 
 // Both operands of the weight-gradient GEMM are row-contiguous tiles whose column position is
@@ -1843,7 +1848,12 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) wgrad_rows_kernel(WgradArgs
 // 4dh .. 4dh+3, so for a P row it needs exactly one Q row (2a-1+dh).  A step is a pair of P rows
 // (sixteen pixels = one K group); Q rows that fall outside the frame are deposited as zeros.  Wave w owns
 // gradient rows 32w .. 32w+31.  The four workgroups of a split fill one slab between them.
-template <bool XP, bool XQ>
+//
+// BNQ: Q is a gradient that has not been through its layer's BatchNorm backward (Q = du, q_y the
+// layer's raw output; a row becomes scale*dz + A*y + B on its way into LDS).  Every Q row is met by
+// exactly two filter rows; the workgroups of filter rows 1 and 2 between them meet each row once and
+// write the finished rows to dx_out for the data-gradient kernel.
+template <bool XP, bool XQ, bool BNQ>
 __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
   constexpr int C1 = 128, C2 = 64, Ws = 8, WQ = 16, NCB = C2 / 16;
   constexpr int PSP = C1 + 4, PSQ = C2 + 2, P4 = C1 / 4, Q4 = C2 / 4;
@@ -1863,10 +1873,16 @@ __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
     psc = ldg4(g.p_scale + 4 * lp4);
     psh = ldg4(g.p_shift + 4 * lp4);
   }
-  if (XQ && g.q_scale) {
+  if ((XQ || BNQ) && g.q_scale) {
     qsc = ldg4(g.q_scale + 4 * lq4);
     qsh = ldg4(g.q_shift + 4 * lq4);
   }
+  f32x4 qca = qsh, qcb = qsh;
+  if (BNQ) {
+    qca = ldg4(g.q_a + 4 * lq4);
+    qcb = ldg4(g.q_b + 4 * lq4);
+  }
+  const bool writer = BNQ && (dh == 1 || dh == 2);
   // zero pixels left (column -1) and right (column WQ) of the four Q row buffers
   for (int i = threadIdx.x; i < 4 * 2 * PSQ; i += 256) {
     const int slot = i / (2 * PSQ), r = i % (2 * PSQ);
@@ -1895,8 +1911,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
   };
   // a thread moves one 16-byte piece of each of the pair's two P rows and two Q rows
   struct Raw {
-    f32x4 p[2], q[2];
+    f32x4 p[2], q[2], qy[BNQ ? 2 : 1];
     bool qok[2];
+    int64_t qoff[2];
   };
   auto fetch = [&](int64_t p, Raw& raw) {
     const bool pok = p < p1;
@@ -1907,7 +1924,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
       const int hin = 2 * a - 1 + dh;
       raw.qok[h] = pok && hin >= 0 && hin < 2 * Hs;
       raw.p[h] = ldg4(g.P + (pok ? prow * (int64_t)(Ws * C1) : 0) + 4 * threadIdx.x);
-      raw.q[h] = ldg4(g.Q + (raw.qok[h] ? (2 * prow - 1 + dh) * (int64_t)(WQ * C2) : 0) + 4 * threadIdx.x);
+      raw.qoff[h] = (raw.qok[h] ? (2 * prow - 1 + dh) * (int64_t)(WQ * C2) : 0) + 4 * threadIdx.x;
+      raw.q[h] = ldg4(g.Q + raw.qoff[h]);
+      if (BNQ) raw.qy[h] = ldg4(g.q_y + raw.qoff[h]);
     }
   };
   auto deposit = [&](int64_t p, const Raw& raw) {
@@ -1916,6 +1935,16 @@ __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
       const f32x4 pv = XP ? transform(raw.p[h], psc, psh, pslope) : raw.p[h];
       *reinterpret_cast<f32x4*>(&pbuf[p & 1][h][(threadIdx.x / P4) * PSP + 4 * lp4]) = pv;
       f32x4 qv = XQ ? transform(raw.q[h], qsc, qsh, qslope) : raw.q[h];
+      if (BNQ) {
+        const f32x4 y = raw.qy[h];
+        const f32x4 zz = y * qsc + qsh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dz = zz[e] > 0.f ? qv[e] : qv[e] * LRELU_SLOPE;
+          qv[e] = fmaf(qsc[e], dz, fmaf(qca[e], y[e], qcb[e]));
+        }
+        if (writer && raw.qok[h]) *reinterpret_cast<f32x4*>(g.dx_out + raw.qoff[h]) = qv;
+      }
       qv = zero_unless(qv, raw.qok[h]);
       float* d = &qbuf[p & 1][h][(1 + threadIdx.x / Q4) * PSQ + 4 * lq4];     // 8-byte aligned (PSQ is even)
       *reinterpret_cast<float2*>(d) = make_float2(qv[0], qv[1]);
@@ -2160,7 +2189,9 @@ extern "C" int64_t dvae_conv_wgrad_ws_floats(int64_t N, int64_t Hs, int64_t Ws, 
 static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float* p_shift, int p_act,
                               const float* Q, const float* q_scale, const float* q_shift, int q_act,
                               float* dw, float* ws, int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2,
-                              const float* p_y, const float* p_a, const float* p_b, dvae_stream_t stream) {
+                              const float* p_y, const float* p_a, const float* p_b, dvae_stream_t stream,
+                              const float* q_y = nullptr, const float* q_a = nullptr, const float* q_b = nullptr,
+                              float* dx_out = nullptr) {
   DVAE_REQUIRE(N > 0 && C1 > 0 && C2 > 0, "conv4s2_wgrad: empty");
   DVAE_REQUIRE(is_pow2(Hs) && is_pow2(Ws), "conv4s2_wgrad: Hs and Ws must be powers of two");
   DVAE_REQUIRE(C1 % 4 == 0, "conv4s2_wgrad: C1 must be a multiple of 4 (C1=%ld)", (long)C1);
@@ -2176,11 +2207,16 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
   g.slab = ws; g.Mtot = N * Hs * Ws; g.Hs = (int)Hs; g.Ws = (int)Ws; g.lh = ilog2(Hs); g.lw = ilog2(Ws);
   g.C1 = (int)C1; g.C2 = (int)C2; g.NC = (int)(16 * C2);
   g.p_y = p_y; g.p_a = p_a; g.p_b = p_b;
+  g.q_y = q_y; g.q_a = q_a; g.q_b = q_b; g.dx_out = dx_out;
   DVAE_REQUIRE(p_y == nullptr || (C2 == 1 && p_scale && p_shift && p_a && p_b),
                "conv4s2_wgrad: a BatchNorm-backward P needs a single-channel Q and scale, shift, A, B");
   const WgradPlan p = wgrad_plan(g.Mtot, Ws, C1, C2, Hs);
   g.ktiles_per_split = p.ktiles_per_split;
   hipStream_t s = ST(stream);
+  DVAE_REQUIRE(q_y == nullptr || (p.bm == -2 && q_scale && q_shift && q_a && q_b && dx_out && aligned16(q_y) &&
+                                  aligned16(q_a) && aligned16(q_b) && aligned16(dx_out)),
+               "conv4s2_wgrad: a BatchNorm-backward Q is only taken where dvae_conv4s2_wgrad_bnq_supported says so, "
+               "with y, scale, shift, A, B and dx_out, 16-byte aligned");
   if (p.bm == -3) {
     DVAE_REQUIRE((!p_scale || (aligned16(p_scale) && aligned16(p_shift))) && (!q_scale || (aligned16(q_scale) && aligned16(q_shift))),
                  "conv4s2_wgrad: scale/shift vectors must be 16-byte aligned");
@@ -2196,10 +2232,13 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
                  "conv4s2_wgrad: scale/shift vectors must be 16-byte aligned");
     const dim3 grid((unsigned)p.split * 4);
     const bool xp = p_scale != nullptr || p_act != DVAE_ACT_NONE, xq = q_scale != nullptr || q_act != DVAE_ACT_NONE;
-    if (xp && xq) hipLaunchKernelGGL((wgrad_rows8_kernel<true, true>), grid, dim3(256), 0, s, g);
-    else if (xp) hipLaunchKernelGGL((wgrad_rows8_kernel<true, false>), grid, dim3(256), 0, s, g);
-    else if (xq) hipLaunchKernelGGL((wgrad_rows8_kernel<false, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((wgrad_rows8_kernel<false, false>), grid, dim3(256), 0, s, g);
+    if (g.q_y != nullptr) {
+      if (xp) hipLaunchKernelGGL((wgrad_rows8_kernel<true, false, true>), grid, dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((wgrad_rows8_kernel<false, false, true>), grid, dim3(256), 0, s, g);
+    } else if (xp && xq) hipLaunchKernelGGL((wgrad_rows8_kernel<true, true, false>), grid, dim3(256), 0, s, g);
+    else if (xp) hipLaunchKernelGGL((wgrad_rows8_kernel<true, false, false>), grid, dim3(256), 0, s, g);
+    else if (xq) hipLaunchKernelGGL((wgrad_rows8_kernel<false, true, false>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((wgrad_rows8_kernel<false, false, false>), grid, dim3(256), 0, s, g);
   } else if (p.bm == -1) {
     DVAE_REQUIRE((!p_scale || (aligned16(p_scale) && aligned16(p_shift))) && (!q_scale || (aligned16(q_scale) && aligned16(q_shift))),
                  "conv4s2_wgrad: scale/shift vectors must be 16-byte aligned");
@@ -2270,6 +2309,20 @@ extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, cons
                                       dvae_stream_t stream) {
   return conv4s2_wgrad_impl(P, p_scale, p_shift, p_act, Q, q_scale, q_shift, q_act, dw, ws, N, Hs, Ws, C1, C2, nullptr,
                             nullptr, nullptr, stream);
+}
+
+extern "C" int dvae_conv4s2_wgrad_bnq_supported(int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2) {
+  return wgrad_plan(N * Hs * Ws, Ws, C1, C2, Hs).bm == -2;
+}
+
+extern "C" int dvae_conv4s2_wgrad_bnq_f32(const float* P, const float* p_scale, const float* p_shift, int p_act,
+                                          const float* du, const float* q_y, const float* q_scale,
+                                          const float* q_shift, const float* q_a, const float* q_b, float* dx_out,
+                                          float* dw, float* ws, int64_t N, int64_t Hs, int64_t Ws, int64_t C1,
+                                          int64_t C2, dvae_stream_t stream) {
+  DVAE_REQUIRE(q_y != nullptr, "conv4s2_wgrad_bnq: q_y is null");
+  return conv4s2_wgrad_impl(P, p_scale, p_shift, p_act, du, q_scale, q_shift, DVAE_ACT_NONE, dw, ws, N, Hs, Ws, C1, C2,
+                            nullptr, nullptr, nullptr, stream, q_y, q_a, q_b, dx_out);
 }
 
 extern "C" int dvae_conv4s2_wgrad_bnp_f32(const float* du, const float* p_y, const float* p_scale, const float* p_shift,

@@ -235,9 +235,15 @@ class DecoderCNN(torch.autograd.Function):
                 du, parts, dy = ops.conv4s2_dgrad_bnstat_bnin(du, ys[l], affs[l], ca, cb, wp, ys[l - 1], affs[l - 1])
                 d_dec[l] = ops.conv4s2_wgrad(pin, psc, psh, pact, dy, None, None, ops.ACT_NONE)
                 continue
-            d_gamma[l], d_beta[l] = ops.bn_bwd(du, ys[l], sc, sh, mean, invstd, ctx.gammas[l], parts)
-            dy = du
-            d_dec[l] = ops.conv4s2_wgrad(pin, psc, psh, pact, dy, None, None, ops.ACT_NONE)
+            if parts is not None and ops.conv4s2_wgrad_bnq_supported(pin, du.shape[-1]):
+                # here it is the weight-gradient kernel that takes du through the BatchNorm backward as it
+                # loads it, and hands the finished dL/dy to the data gradient
+                d_gamma[l], d_beta[l], ca, cb = ops.bn_bwd_coeffs(parts, affs[l], du.numel() // du.shape[-1])
+                d_dec[l], dy = ops.conv4s2_wgrad_bnq(pin, psc, psh, pact, du, ys[l], affs[l], ca, cb)
+            else:
+                d_gamma[l], d_beta[l] = ops.bn_bwd(du, ys[l], sc, sh, mean, invstd, ctx.gammas[l], parts)
+                dy = du
+                d_dec[l] = ops.conv4s2_wgrad(pin, psc, psh, pact, dy, None, None, ops.ACT_NONE)
             if l > 0 and _fuse_bn_stats(ys[l - 1].shape[-1]):
                 du, parts = ops.conv4s2_dgrad_bnstat(dy, wp, ys[l - 1], affs[l - 1])
             else:

@@ -444,6 +444,28 @@ def conv4s2_wgrad_bnp(du: Tensor, p_y: Tensor, p_aff, coef_a: Tensor, coef_b: Te
     return dw
 
 
+def conv4s2_wgrad_bnq_supported(P: Tensor, C2: int) -> bool:
+    N, Hs, Ws, C1 = P.shape
+    return bool(lib.dvae_conv4s2_wgrad_bnq_supported(N, Hs, Ws, C1, C2))
+
+
+def conv4s2_wgrad_bnq(P: Tensor, p_scale, p_shift, p_act: int, du: Tensor, q_y: Tensor, q_aff, coef_a: Tensor,
+                      coef_b: Tensor):
+    """conv4s2_wgrad whose Q = du still needs its layer's BatchNorm backward; returns (dw, dx) with dx the
+    finished dL/d(q_y)."""
+    _chk(P, p_scale, p_shift, du, q_y, coef_a, coef_b, *q_aff)
+    N, Hs, Ws, C1 = P.shape
+    C2 = du.shape[3]
+    assert du.shape == q_y.shape == (N, 2 * Hs, 2 * Ws, C2)
+    dw = torch.empty(C1, C2, 4, 4, dtype=torch.float32, device=P.device)
+    dx = torch.empty_like(du)
+    ws = workspace(lib.dvae_conv_wgrad_ws_floats(N, Hs, Ws, C1, C2), P.device)
+    check(lib.dvae_conv4s2_wgrad_bnq_f32(_p(P), _p(p_scale), _p(p_shift), p_act, _p(du), _p(q_y), _p(q_aff[0]),
+                                         _p(q_aff[1]), _p(coef_a), _p(coef_b), _p(dx), _p(dw), _p(ws), N, Hs, Ws, C1,
+                                         C2, _stream()), 'conv4s2_wgrad_bnq')
+    return dw, dx
+
+
 def conv4s2_bnin_supported(x: Tensor, Cout: int) -> bool:
     N, H, W, Cin = x.shape
     return bool(lib.dvae_conv4s2_bnin_supported(H, W, Cin, Cout))

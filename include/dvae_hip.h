@@ -253,6 +253,16 @@ int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, const float* p_
 int dvae_conv4s2_wgrad_bnp_f32(const float* du, const float* p_y, const float* p_scale, const float* p_shift,
                                const float* p_a, const float* p_b, const float* Q, float* dw, float* ws,
                                int64_t N, int64_t Hs, int64_t Ws, int64_t C1, dvae_stream_t stream);
+/* dvae_conv4s2_wgrad_f32 whose Q = dL/d(activation) has not been through its layer's BatchNorm backward
+ * (weight gradient of a decoder block, models/decoders.py:40-45): du, the layer's raw output q_y, its
+ * forward affine and the vectors of dvae_bn_bwd_coeffs_f32.  Q becomes scale*dz + A*y + B as it is
+ * loaded, and the finished dL/dy is also written to dx_out (shaped like du) for the data-gradient call
+ * that follows.  Only where dvae_conv4s2_wgrad_bnq_supported says so; otherwise -EINVAL. */
+int dvae_conv4s2_wgrad_bnq_supported(int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2);
+int dvae_conv4s2_wgrad_bnq_f32(const float* P, const float* p_scale, const float* p_shift, int p_act,
+                               const float* du, const float* q_y, const float* q_scale, const float* q_shift,
+                               const float* q_a, const float* q_b, float* dx_out, float* dw, float* ws,
+                               int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2, dvae_stream_t stream);
 /* Final decoder layer (models/decoders.py:49-53,67-68): ConvTranspose2d(Cin -> 1, bias) + sigmoid.
  * x [N,H,W,Cin] (+ load-time transform), w torch layout [Cin][1][4][4], y [N,2H,2W]. Cin%4==0. */
 int dvae_deconv4s2_final_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,

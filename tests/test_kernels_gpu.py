@@ -616,6 +616,26 @@ def test_first_layer_wgrad_that_applies_the_bn_backward_of_its_gradient(ops, N, 
     assert rel_err(got, dw64) < 5e-6 and rel_err(ref, dw64) < 5e-6
 
 
+@pytest.mark.parametrize('N', [3, 40])
+def test_wgrad_that_applies_the_bn_backward_of_its_gradient_operand(ops, N):
+    """conv4s2_wgrad_bnq (128 x 64 on 8-wide P) against bn_bwd followed by conv4s2_wgrad."""
+    Hs, C1, C2 = 8, 128, 64
+    du, y, gamma, aff, dz, xhat, sc = _bn_case((N, 2 * Hs, 2 * Hs, C2), C2, 130)
+    M = N * 4 * Hs * Hs
+    Pt = rnd(N, Hs, Hs, C1, seed=135)
+    psc, psh = dev(1 + 0.3 * rnd(C1, seed=136)), dev(0.2 * rnd(C1, seed=137))
+    assert ops.conv4s2_wgrad_bnq_supported(dev(Pt), C2)
+    parts = ops.bn_bwd_reduce(dev(du), dev(y), aff)
+    dg, db, ca, cb = ops.bn_bwd_coeffs(parts, aff, M)
+    got_dw, got_dx = ops.conv4s2_wgrad_bnq(dev(Pt), psc, psh, ops.ACT_LRELU, dev(du), dev(y), aff, ca, cb)
+    ref_dx = dev(du)
+    ops.bn_bwd(ref_dx, dev(y), *aff, dev(gamma))
+    ref_dw = ops.conv4s2_wgrad(dev(Pt), psc, psh, ops.ACT_LRELU, ref_dx, None, None, ops.ACT_NONE)
+    dx64 = sc * (dz - dz.sum(dim=(0, 1, 2)) / M - xhat * (dz * xhat).sum(dim=(0, 1, 2)) / M)
+    assert rel_err(got_dx, dx64) < 2e-6 and rel_err(ref_dx, dx64) < 2e-6
+    assert rel_err(got_dw, ref_dw) < 5e-6
+
+
 # ------------------------------------------------------------------ data gradient + BatchNorm-backward statistics
 @pytest.mark.parametrize('kind,N,H,Cin,Cout', [('conv', 5, 32, 16, 32), ('conv', 3, 64, 1, 16), ('conv', 3, 64, 1, 32),
                                                ('conv', 4, 32, 32, 64), ('conv', 2, 64, 32, 64),
