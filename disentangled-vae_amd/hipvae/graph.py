@@ -80,6 +80,21 @@ class GraphedTrainStep:
         return self.losses
 
 
+def broadcast_flat(tensors, group=None, src: int = 0):
+    """Rank `src`'s values of all tensors to every rank, one collective per dtype (tensors are packed into
+    a flat buffer and unpacked in place)."""
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t.data)
+    for ts in by_dtype.values():
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for t in ts:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+
+
 class GraphedDataParallelStep(GraphedTrainStep):
     """The captured step for one replica of a data-parallel job (one process per GPU).
 
@@ -103,8 +118,7 @@ class GraphedDataParallelStep(GraphedTrainStep):
         self.use_avg = dist.get_backend(process_group) == 'nccl'
         self.params = [p for p in model.parameters() if p.requires_grad]
         if broadcast_parameters:
-            for t in list(model.parameters()) + list(model.buffers()):
-                dist.broadcast(t.data, src=0, group=process_group)
+            broadcast_flat(list(model.parameters()) + list(model.buffers()), process_group)
         n = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.params[0].device)
         self.views, off = [], 0
