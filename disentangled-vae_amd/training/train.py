@@ -118,7 +118,7 @@ def main(argv=None):
         render_device=torch.device('cuda', torch.cuda.current_device()) if args.gpu_render else None)
     trainer = create_trainer(cfg, train_loader, val_loader)
     if args.hip_graph:
-        trainer.use_graph = not trainer.distributed
+        trainer.use_graph = True
     history = trainer.train(resume=args.resume)
     if rank == 0:
         print(f"Results saved to: {trainer.results_dir}")

@@ -67,8 +67,8 @@ class Trainer:
 
     def __init__(self, model: nn.Module, config: ExperimentConfig, train_loader, val_loader,
                  device: Optional[torch.device] = None, use_graph: Optional[bool] = None):
-        """use_graph: replay the training step as a captured hipGraph (single process only); default
-        from the environment variable DVAE_HIPGRAPH (off unless it is '1')."""
+        """use_graph: replay the training step as a captured hipGraph (with several ranks: two graphs around
+        one gradient all-reduce); default from the environment variable DVAE_HIPGRAPH (off unless '1')."""
         self.config = config
         self.train_loader = train_loader
         self.val_loader = val_loader
@@ -101,7 +101,7 @@ class Trainer:
             self.grad_sync = GradSync(self.model)
         if use_graph is None:
             use_graph = os.environ.get('DVAE_HIPGRAPH', '0') == '1'
-        self.use_graph = bool(use_graph) and not self.distributed
+        self.use_graph = bool(use_graph)
         self._graphs = {}                 # (batch shape, beta) -> GraphedTrainStep
 
         self.checkpoint_dir = os.path.join(t.checkpoint_dir, config.name)
@@ -174,14 +174,25 @@ class Trainer:
         """The same step replayed from a hipGraph captured for this batch shape and beta; beta is a
         constant of the captured graph, so each annealing value gets its own capture (one per epoch
         during warm-up) and only the newest two are kept."""
-        from hipvae.graph import GraphedTrainStep
+        from hipvae.graph import GraphedDataParallelStep, GraphedTrainStep
         key = (tuple(video.shape), float(beta))
         g = self._graphs.get(key)
         if g is None:
             while len(self._graphs) >= 2:
                 self._graphs.pop(next(iter(self._graphs)))
-            g = GraphedTrainStep(self.model, self.optimizer, lambda m, v: self._compute_loss(v, beta)[0], video,
-                                 gradient_clip=self.config.training.gradient_clip)
+            loss_of = lambda m, v: self._compute_loss(v, beta)[0]
+            clip = self.config.training.gradient_clip
+            if self.distributed:
+                # several ranks: two graphs around one all-reduce of the flat gradient buffer.  The hooks
+                # of the eager path must not fire under capture; the parameters were broadcast when the
+                # Trainer was built and every rank has taken the same steps since.
+                if self.grad_sync is not None:
+                    self.grad_sync.remove()
+                    self.grad_sync = None
+                g = GraphedDataParallelStep(self.model, self.optimizer, loss_of, video, gradient_clip=clip,
+                                            broadcast_parameters=False)
+            else:
+                g = GraphedTrainStep(self.model, self.optimizer, loss_of, video, gradient_clip=clip)
             self._graphs[key] = g
         return g(video)
 
