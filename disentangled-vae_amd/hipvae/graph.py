@@ -156,11 +156,13 @@ class GraphedDataParallelStep(GraphedTrainStep):
         return losses
 
     def _capture(self):
+        # thread-local capture mode: the process group's watchdog thread polls events of finished
+        # collectives while this thread captures, which the default (global) mode may refuse
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.losses = self._backward_part()
         self.graph_update = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_update, pool=self.graph.pool()):
+        with torch.cuda.graph(self.graph_update, pool=self.graph.pool(), capture_error_mode='thread_local'):
             self._update_part()
 
     def __call__(self, video: torch.Tensor):
