@@ -102,13 +102,18 @@ class KernelTimer:
         setattr(self.ops, name, wrapped)
 
     def install(self):
-        def tile(c, rows=None, phases=1):
-            """tile the launcher picks: by output channels, narrowed while fewer than 256 workgroups"""
+        def tile(c, rows=None, phases=1, stats=True):
+            """tile the launcher picks: by output channels, narrowed while fewer than 256 workgroups; a
+            layer without statistics whose 128-wide tiles end in a partly filled round of the 512
+            workgroup slots finishes with a second launch of 64-wide tiles"""
             bn = 128 if c > 64 else (64 if c > 32 else 32)
             if rows is not None:
                 row_tiles = -(-rows // 128) * phases
                 while bn > 32 and row_tiles * -(-c // bn) < 256:
                     bn //= 2
+                tiles = row_tiles * -(-c // 128)
+                if bn == 128 and not stats and tiles >= 512 and 512 <= 5 * (tiles % 512) and 10 * (tiles % 512) <= 3584:
+                    return 'T128+T64'
             return f'T{bn}'
 
         def conv_key(x, sc, sh, act, wp, stats):
@@ -119,7 +124,7 @@ class KernelTimer:
             fl = 2.0 * N * (H // 2) * (W // 2) * Cout * 16 * Cin
             if (Cin, Cout) in ((32, 64), (16, 32)) and 32 <= W <= 64:     # few channels: rows through an LDS ring
                 return f"conv_rows_kernel<{Cin},{Cout}>", fl, 'flop'
-            return f"conv_fwd_kernel<{tile(Cout, N * (H // 2) * (W // 2))},conv>", fl, 'flop'
+            return f"conv_fwd_kernel<{tile(Cout, N * (H // 2) * (W // 2), 1, stats)},conv>", fl, 'flop'
 
         def conv_bn_key(x, wp, bn_y, aff):
             key, work, unit = conv_key(x, None, None, 0, wp, True)
@@ -143,7 +148,7 @@ class KernelTimer:
                 return "deconv_rows8_kernel<128>", fl, 'flop'
             if (Cin, Cout) in ((32, 16), (64, 32)) and 16 <= W <= 32:   # few channels: rows through an LDS ring
                 return f"deconv_rows_kernel<{Cin},{Cout}>", fl, 'flop'
-            return f"conv_fwd_kernel<{tile(Cout, N * H * W, 4)},deconv>", fl, 'flop'
+            return f"conv_fwd_kernel<{tile(Cout, N * H * W, 4, stats)},deconv>", fl, 'flop'
 
         def wgrad_key(P, ps, ph, pa, Q, qs, qh, qa):
             N, Hs, Ws, C1 = P.shape

@@ -102,6 +102,7 @@ struct ConvArgs {
   const float* in_a;
   const float* in_b;
   float* dx_out;
+  int mt0;          // tiled kernels: first M tile of this launch (a layer may be split over two launches)
   int round_bf16;   // row-ring kernels in bf16 mode: operands rounded to bf16 on their way into registers / LDS
 };
 
@@ -269,7 +270,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
 #pragma unroll
   for (int j = 0; j < T::TN; ++j) s1[j] = s2[j] = 0.f;
 
-  for (int mt = bx; mt < g.mtiles; mt += gx) {
+  for (int mt = g.mt0 + bx; mt < g.mtiles; mt += gx) {
     const int64_t m0 = (int64_t)mt * T::BM;
     la.set_tile(m0);
     f32x16 acc[T::TM][T::TN];
@@ -1093,8 +1094,14 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   const bool bns = g.bn_y != nullptr;
 #define LAUNCH(TILE, C1FLAG)                                                                         \
   {                                                                                                  \
-    g.mtiles = (int)ceil_div64(g.M, TILE::BM);                                                       \
-    int gx = g.mtiles < CONV_MAX_PARTS ? g.mtiles : CONV_MAX_PARTS;                                  \
+    if (mt_end < 0) {                                                                                \
+      g.mt0 = 0;                                                                                     \
+      g.mtiles = (int)ceil_div64(g.M, TILE::BM);                                                     \
+    } else {                                                                                         \
+      g.mt0 = mt_begin;                                                                              \
+      g.mtiles = mt_end;                                                                             \
+    }                                                                                                \
+    int gx = g.mtiles - g.mt0 < CONV_MAX_PARTS ? g.mtiles - g.mt0 : CONV_MAX_PARTS;                  \
     dim3 grid(gx * phases, (unsigned)ceil_div64(g.Cout, TILE::BN), 1);                               \
     if (bns && !(C1FLAG)) {                                                                          \
       if (bf)                                                                                        \
@@ -1106,6 +1113,7 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     else                                                                                             \
       hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG, false, false>), grid, dim3(256), 0, stream, g); \
   }
+  int mt_begin = 0, mt_end = -1;       // M-tile range of the next LAUNCH (-1: the whole layer)
   typedef Tile<128, 128, 2, 2, true, true> T128;
   typedef Tile<128, 64, 4, 1, true, true> T64;
   typedef Tile<128, 32, 4, 1, true, true> T32;
@@ -1206,6 +1214,26 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     const int64_t row_tiles = ceil_div64(g.M, 128) * phases;
     int bn = g.Cout > 64 ? 128 : (g.Cout > 32 ? 64 : 32);
     while (bn > 32 && row_tiles * ceil_div64(g.Cout, bn) < 256) bn >>= 1;
+    // 128-wide tiles that fill the chip's 512 workgroup slots a whole number of times and then leave
+    // between a fifth and seven tenths of a round: the remainder goes to a second launch with 64-wide
+    // tiles, which is a shorter last round than a mostly idle one.  (Not with statistics: the partial
+    // rows are numbered per launch.)
+    const int64_t tiles128 = row_tiles * ceil_div64(g.Cout, 128);
+    const int64_t full = tiles128 / 512, rest = tiles128 % 512;
+    if (bn == 128 && g.stats == nullptr && full >= 1 && 5 * rest >= 512 && 10 * rest <= 7 * 512) {
+      const int64_t per_mt = phases * ceil_div64(g.Cout, 128);          // workgroups per M tile
+      const int split_mt = (int)(full * 512 / per_mt);
+      if (split_mt > 0 && split_mt < (int)ceil_div64(g.M, 128)) {
+        mt_begin = 0;
+        mt_end = split_mt;
+        LAUNCH(T128, false)
+        mt_begin = split_mt;
+        mt_end = (int)ceil_div64(g.M, 128);
+        LAUNCH(T64, false)
+        DVAE_LAUNCH_CHECK(name);
+        return 0;
+      }
+    }
     if (bn == 128) {
       LAUNCH(T128, false)
     } else if (bn == 64) {
