@@ -15,12 +15,13 @@ struct GemmArgs {
   int64_t lda, ldb, ldc;
   int64_t M, N, K;
   int act, accumulate, ktiles_per_split;
+  int tm0;      // first row of tiles of this launch (a product may be split over two launches)
 };
 
 template <class T, int KIND, bool BF>
 __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * Core<T, BF>::STAGE];
-  const int64_t m0 = (int64_t)blockIdx.y * T::BM, n0 = (int64_t)blockIdx.x * T::BN;
+  const int64_t m0 = (int64_t)(blockIdx.y + g.tm0) * T::BM, n0 = (int64_t)blockIdx.x * T::BN;
   const int ktiles = (int)((g.K + 31) / 32);
   const int kt_begin = blockIdx.z * g.ktiles_per_split;
   int kt_end = kt_begin + g.ktiles_per_split;
@@ -175,12 +176,25 @@ static bool small_gemm_shape(int64_t M, int64_t N, int64_t K) {
   return tiles <= 1024 && tiles * K <= (1 << 20);
 }
 
-static int choose_split(int64_t tiles, int64_t ktiles) {
-  int64_t s = 512 / (tiles > 0 ? tiles : 1);
-  if (s > ktiles / 4) s = ktiles / 4;
-  if (s > 32) s = 32;
-  if (s < 1) s = 1;
-  return (int)s;
+// Split of K over workgroups.  The chip holds 512 workgroups of this kernel at a time, so a launch
+// costs (rounds of 512) x (k-tiles per workgroup); each split adds a pass over the M x N partials,
+// priced in the same unit: one round of one k-tile is ~0.54 GFLOP ~ 4.9 us, which is the time HBM
+// needs for ~5 M floats of slab traffic.
+static int choose_split(int64_t tiles, int64_t ktiles, int64_t mn) {
+  if (tiles >= 512) return 1;
+  int64_t smax = ktiles / 4;
+  if (smax > 32) smax = 32;
+  int best = 1;
+  double best_cost = (double)ktiles;            // one round, no partials
+  for (int64_t s = 2; s <= smax; ++s) {
+    const int64_t rounds = (tiles * s + 511) / 512;
+    const double cost = (double)rounds * (double)((ktiles + s - 1) / s) + (double)(s + 1) * (double)mn / 5.0e6;
+    if (cost < best_cost * 0.97) {
+      best_cost = cost;
+      best = (int)s;
+    }
+  }
+  return best;
 }
 
 struct Plan {
@@ -196,7 +210,7 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K) {
   p.tm = ceil_div64(M, BM);
   p.tn = ceil_div64(N, BN);
   const int64_t ktiles = ceil_div64(K, 32);
-  p.split = choose_split(p.tm * p.tn, ktiles);
+  p.split = choose_split(p.tm * p.tn, ktiles, M * N);
   p.ktiles_per_split = (int)ceil_div64(ktiles, p.split);
   p.split = (int)ceil_div64(ktiles, p.ktiles_per_split);
   return p;
@@ -229,6 +243,27 @@ static int launch_gemm(const char* name, GemmArgs g, float* ws, hipStream_t stre
   const dim3 grid((unsigned)p.tn, (unsigned)p.tm, (unsigned)p.split);
   constexpr bool AKC = KIND != G_TN, BKC = KIND == G_NT;
   const bool bf = dvae_mfma_precision() == DVAE_PRECISION_BF16;
+  g.tm0 = 0;
+  // tiles that fill the 512 workgroup slots a whole number of times and then leave between a fifth and
+  // seven tenths of a round: the remaining rows of tiles go to a second launch with 64-wide tiles,
+  // which is a shorter last round than a mostly idle one
+  const int64_t tiles = p.tm * p.tn, full = tiles / 512, rest = tiles % 512;
+  if (KIND == G_NT && !p.small_m && p.split == 1 && full >= 1 && 5 * rest >= 512 && 10 * rest <= 7 * 512) {
+    const int64_t head_tm = full * 512 / p.tn;
+    if (head_tm > 0 && head_tm < p.tm) {
+      typedef Tile<128, 128, 2, 2, true, true> Wide;
+      typedef Tile<128, 64, 4, 1, true, true> Narrow;
+      const dim3 head((unsigned)p.tn, (unsigned)head_tm, 1);
+      const dim3 tail((unsigned)ceil_div64(g.N, 64), (unsigned)(p.tm - head_tm), 1);
+      if (bf) hipLaunchKernelGGL((gemm_kernel<Wide, G_NT, true>), head, dim3(256), 0, stream, g);
+      else hipLaunchKernelGGL((gemm_kernel<Wide, G_NT, false>), head, dim3(256), 0, stream, g);
+      g.tm0 = (int)head_tm;
+      if (bf) hipLaunchKernelGGL((gemm_kernel<Narrow, G_NT, true>), tail, dim3(256), 0, stream, g);
+      else hipLaunchKernelGGL((gemm_kernel<Narrow, G_NT, false>), tail, dim3(256), 0, stream, g);
+      DVAE_LAUNCH_CHECK(name);
+      return 0;
+    }
+  }
   if (p.small_m) {
     if (bf) hipLaunchKernelGGL((gemm_kernel<Tile<32, 128, 1, 4, AKC, BKC>, KIND, true>), grid, dim3(256), 0, stream, g);
     else hipLaunchKernelGGL((gemm_kernel<Tile<32, 128, 1, 4, AKC, BKC>, KIND, false>), grid, dim3(256), 0, stream, g);
