@@ -936,11 +936,64 @@ permute3_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t D
   }
 }
 
+// (0,2,1): D0 independent D1 x D2 transposes through 32x32 LDS tiles, both sides coalesced
+__global__ void __launch_bounds__(256)
+transpose_inner_kernel(const float* __restrict__ in, float* __restrict__ out, int D1, int D2, int t1, int t2) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.x;
+  const int a = b / (t1 * t2), r = b - a * (t1 * t2);
+  const int i0 = (r / t2) * 32, j0 = (r % t2) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* src = in + (int64_t)a * D1 * D2;
+  float* dst = out + (int64_t)a * D1 * D2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = i0 + ty + 8 * k, j = j0 + tx;
+    if (i < D1 && j < D2) tile[ty + 8 * k][tx] = src[(int64_t)i * D2 + j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = j0 + ty + 8 * k, i = i0 + tx;
+    if (i < D1 && j < D2) dst[(int64_t)j * D1 + i] = tile[tx][ty + 8 * k];
+  }
+}
+
+// (1,0,2) with rows of whole float4: out[b][a][:] = in[a][b][:]
+__global__ void __launch_bounds__(256)
+swap_outer_kernel(const float4* __restrict__ in, float4* __restrict__ out, int D0, int D1, int V, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / V;
+    const int c = (int)(i - row * V);
+    const int a = (int)(row % D0), b = (int)(row / D0);          // output row (b, a)
+    out[i] = in[((int64_t)a * D1 + b) * V + c];
+  }
+}
+
 extern "C" int dvae_permute3_f32(const float* in, float* out, int64_t D0, int64_t D1, int64_t D2, int p0, int p1,
                                  int p2, dvae_stream_t stream) {
   DVAE_REQUIRE(D0 > 0 && D1 > 0 && D2 > 0, "permute3: empty");
   DVAE_REQUIRE(p0 >= 0 && p0 < 3 && p1 >= 0 && p1 < 3 && p2 >= 0 && p2 < 3 && p0 != p1 && p0 != p2 && p1 != p2,
                "permute3: (%d,%d,%d) is not a permutation", p0, p1, p2);
+  if (p0 == 0 && p1 == 2 && p2 == 1 && D1 > 1 && D2 > 1 && D1 < (1 << 30) && D2 < (1 << 30)) {
+    const int64_t t1 = ceil_div64(D1, 32), t2 = ceil_div64(D2, 32);
+    if (D0 * t1 * t2 < (1LL << 31) && t1 * t2 < (1LL << 31)) {
+      hipLaunchKernelGGL(transpose_inner_kernel, dim3((unsigned)(D0 * t1 * t2)), dim3(256), 0, ST(stream), in, out,
+                         (int)D1, (int)D2, (int)t1, (int)t2);
+      DVAE_LAUNCH_CHECK("permute3");
+      return 0;
+    }
+  }
+  if (p0 == 1 && p1 == 0 && p2 == 2 && D2 % 4 == 0 && D0 < (1 << 30) && D1 < (1 << 30) && D2 < (1LL << 32) &&
+      (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+    const int64_t total = D0 * D1 * (D2 / 4);
+    int64_t nbv = ceil_div64(total, 256);
+    if (nbv > 8192) nbv = 8192;
+    hipLaunchKernelGGL(swap_outer_kernel, dim3((unsigned)nbv), dim3(256), 0, ST(stream), (const float4*)in, (float4*)out,
+                       (int)D0, (int)D1, (int)(D2 / 4), total);
+    DVAE_LAUNCH_CHECK("permute3");
+    return 0;
+  }
   int64_t nb = ceil_div64(D0 * D1 * D2, 256);
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(permute3_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), in, out, D0, D1, D2, p0, p1, p2);

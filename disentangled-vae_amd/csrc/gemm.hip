@@ -37,11 +37,11 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
   } else if (KIND == G_NN) {
     KCLoader<T::A_V4> la(g.A, g.lda, g.M, g.K, m0);
     RCLoader<T::B_V4, T::BN, BF> lb(g.B, g.ldb, g.N, g.K, n0);
-    gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
+    gemm_mainloop_ahead2<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
   } else {
     RCLoader<T::A_V4, T::BM, BF> la(g.A, g.lda, g.M, g.K, m0);
     RCLoader<T::B_V4, T::BN, BF> lb(g.B, g.ldb, g.N, g.K, n0);
-    gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
+    gemm_mainloop_ahead2<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
   }
 
   if (g.slab) {
@@ -189,7 +189,7 @@ static int choose_split(int64_t tiles, int64_t ktiles, int64_t mn) {
   for (int64_t s = 2; s <= smax; ++s) {
     const int64_t rounds = (tiles * s + 511) / 512;
     const double cost = (double)rounds * (double)((ktiles + s - 1) / s) + (double)(s + 1) * (double)mn / 5.0e6;
-    if (cost < best_cost * 0.97) {
+    if (cost < best_cost * 0.9) {
       best_cost = cost;
       best = (int)s;
     }

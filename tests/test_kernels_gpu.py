@@ -681,3 +681,15 @@ def test_dgrad_with_fused_bn_backward_statistics(ops, kind, N, H, Cin, Cout):
         b = plain.clone()
         dg2, db2 = ops.bn_bwd(b, dev(y), *aff, dev(gamma))
         assert rel_err(a, b) < 2e-6 and rel_err(dg1, dg2) < 2e-5 and rel_err(db1, db2) < 2e-5
+
+
+# ------------------------------------------------------------------------------- layout helper
+@pytest.mark.parametrize('dims', [(512, 256, 16), (7, 33, 65), (3, 1, 40), (5, 40, 1), (16, 20, 512), (2, 3, 6)])
+@pytest.mark.parametrize('perm', [(0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)])
+def test_permute3_is_exact(ops, dims, perm):
+    """Every permutation of three axes (the tiled-transpose and row-swap paths and the generic one) is a
+    pure data movement: bit-equal to torch's permute."""
+    x = torch.randn(*dims, generator=torch.Generator().manual_seed(5)).cuda()
+    got = ops.permute3(x, dims, perm)
+    assert got.shape == tuple(dims[p] for p in perm)
+    assert torch.equal(got, x.permute(*perm).contiguous())

@@ -1,0 +1,54 @@
+"""Micro-benchmark of the Linear-layer GEMMs on the shapes of the 20x64x64 DisentangledVAE at batch 256,
+one line per (kind, shape).
+
+usage: python tools/bench_gemm.py [--reps 20] [--precision fp32|bf16]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'disentangled-vae_amd'))
+from hipvae import ops  # noqa: E402
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--precision', default='fp32')
+    a = ap.parse_args()
+    ops.set_precision(a.precision)
+    dev = 'cuda'
+    # (rows of the activation, in features, out features) of the Linear layers that matter
+    layers = [(4864, 8192, 512), (5120, 640, 4096), (4864, 512, 1024), (4864, 256, 1024), (5120, 256, 512),
+              (256, 4096, 512)]
+    for M, K, N in layers:
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(N, K, device=dev) * 0.05
+        b = torch.randn(N, device=dev)
+        dy = torch.randn(M, N, device=dev)
+        fl = 2.0 * M * N * K
+        for name, fn in (('nt  y = x w^T + b ', lambda: ops.gemm_nt(x, w, b, ops.ACT_LRELU)),
+                         ('nn  dx = dy w     ', lambda: ops.gemm_nn(dy, w)),
+                         ('tn  dw = dy^T x   ', lambda: ops.gemm_tn(dy, x))):
+            t = timeit(fn, a.reps)
+            print(f'{name} M={M:5d} K={K:5d} N={N:5d}  {t:8.1f} us  {fl / t / 1e6:7.1f} TFLOP/s', flush=True)
+
+
+if __name__ == '__main__':
+    main()
