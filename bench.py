@@ -177,7 +177,9 @@ class KernelTimer:
                 else:
                     K, M = a.shape
                     N = b.shape[1]
-                return f"gemm_kernel<{kind}>", 2.0 * M * N * K, 'flop'
+                tiles16 = -(-M // 16) * -(-N // 16)      # the launcher's rule for its small-product kernel
+                name = 'small_gemm_kernel' if tiles16 <= 1024 and tiles16 * K <= (1 << 20) else 'gemm_kernel'
+                return f"{name}<{kind}>", 2.0 * M * N * K, 'flop'
             return f
 
         def final_key(x, sc, sh, act, w, b, oa):

@@ -44,6 +44,9 @@ def bench_label(name):
     m = re.match(r'void gemm_kernel<Tile<.*?>, (\d), (true|false)>', name)
     if m:
         return f"gemm_kernel<{('nt', 'nn', 'tn')[int(m.group(1))]}>"
+    m = re.match(r'void small_gemm_kernel<(\d), (true|false)>', name)
+    if m:
+        return f"small_gemm_kernel<{('nt', 'nn', 'tn')[int(m.group(1))]}>"
     m = re.match(r'(?:void )?(\w+)', name)
     return m.group(1) if m else None
 
