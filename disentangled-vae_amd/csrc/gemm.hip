@@ -6,6 +6,8 @@
 
 enum { G_NT = 0, G_NN = 1, G_TN = 2 };
 
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
 struct GemmArgs {
   const float* A;
   const float* B;
@@ -65,19 +67,37 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
   }
 }
 
+// Sum of the split-K partials [split][M][N] plus the epilogue.  Four slabs are read per pass with
+// independent loads (a one-slab-at-a-time loop is a chain of dependent memory latencies) and, when the
+// row length allows, four columns per thread; the order of the additions is fixed.
+template <int V>
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float* __restrict__ slab, int split, const float* __restrict__ bias, int act,
                      int accumulate, float* __restrict__ C, int64_t ldc, int64_t M, int64_t N) {
-  const int64_t total = M * N;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int z = 0; z < split; ++z) s += slab[(int64_t)z * total + i];
+  typedef float vec __attribute__((ext_vector_type(V)));
+  const int64_t total = M * N, totalv = total / V;
+  for (int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x; iv < totalv; iv += (int64_t)gridDim.x * 256) {
+    const int64_t i = iv * V;
+    vec s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 4 <= split; z += 4) {
+      s0 += *reinterpret_cast<const vec*>(slab + (int64_t)z * total + i);
+      s1 += *reinterpret_cast<const vec*>(slab + (int64_t)(z + 1) * total + i);
+      s2 += *reinterpret_cast<const vec*>(slab + (int64_t)(z + 2) * total + i);
+      s3 += *reinterpret_cast<const vec*>(slab + (int64_t)(z + 3) * total + i);
+    }
+    for (; z < split; ++z) s0 += *reinterpret_cast<const vec*>(slab + (int64_t)z * total + i);
+    const vec s = (s0 + s1) + (s2 + s3);
     const int64_t m = i / N, n = i - m * N;
-    if (bias) s += bias[n];
-    if (act == DVAE_ACT_LRELU) s = lrelu(s);
     float* p = C + m * ldc + n;
-    if (accumulate) s += *p;
-    *p = s;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float o = s[e];
+      if (bias) o += bias[n + e];
+      if (act == DVAE_ACT_LRELU) o = lrelu(o);
+      if (accumulate) o += p[e];
+      p[e] = o;
+    }
   }
 }
 
@@ -273,16 +293,22 @@ static int launch_gemm(const char* name, GemmArgs g, float* ws, hipStream_t stre
   }
   DVAE_LAUNCH_CHECK(name);
   if (p.split > 1) {
-    int64_t nb = ceil_div64(g.M * g.N, 256);
+    // four columns per thread when rows are whole float4s in the slab (16-byte aligned with its M*N
+    // stride) -- the output pointer is only ever addressed per element
+    const bool v4 = g.N % 4 == 0 && aligned16(ws);
+    int64_t nb = ceil_div64(g.M * g.N / (v4 ? 4 : 1), 256);
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)ws, p.split,
-                       g.bias, g.act, g.accumulate, g.C, g.ldc, g.M, g.N);
+    if (v4)
+      hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)ws, p.split,
+                         g.bias, g.act, g.accumulate, g.C, g.ldc, g.M, g.N);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)ws, p.split,
+                         g.bias, g.act, g.accumulate, g.C, g.ldc, g.M, g.N);
     DVAE_LAUNCH_CHECK(name);
   }
   return 0;
 }
 
-static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" int dvae_gemm_nt_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, int act,
                                 float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, float* ws,
