@@ -487,7 +487,7 @@ def main():
                               'ms_per_step': top['ms_per_step']}
         result['kernels'] = [{k: r[k] for k in ('kernel', 'bound', 'achieved', 'unit', 'frac', 'ms_per_step')}
                              for r in rows[:12]]
-    if args.mode == 'train' and not args.no_extras:
+    if args.mode == 'train' and not args.no_extras and world == 1:
         # the same job's inference rate (eval-mode forward, no_grad) and its bf16-MFMA variant
         model.eval()
         el, _ = measure(infer_step, args.steps, min(args.warmup, 3))

@@ -207,6 +207,79 @@ extern "C" int dvae_recon_loss_fwd_f32(const float* recon, const float* target, 
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// reconstruction metrics of the evaluation loop (reference: evaluation/metrics.py:14-22, :48-50) in
+// one pass over the two clips: a thread walks one float4 column of a clip through time, so every
+// element is read once and the previous frame stays in registers.
+//   out[0] = mean((recon - target)^2)          out[1] = 10 log10(max_val^2 / out[0])  (+inf when 0)
+//   out[2] = mean(|recon[:,1:] - recon[:,:-1]|)  (NaN when T == 1: the mean of no elements, as in torch)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+recon_metrics_kernel(const float4* __restrict__ recon, const float4* __restrict__ target,
+                     double* __restrict__ partials, int64_t total, int T, int64_t P4) {
+  __shared__ double red[4];
+  double s_sq = 0.0, s_ab = 0.0;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t b = idx / P4, p = idx - b * P4;
+    const float4* r = recon + b * T * P4 + p;
+    const float4* x = target + b * T * P4 + p;
+    float4 rp = r[0];
+    const float4 x0 = x[0];
+    float sq = (rp.x - x0.x) * (rp.x - x0.x) + (rp.y - x0.y) * (rp.y - x0.y) + (rp.z - x0.z) * (rp.z - x0.z) +
+               (rp.w - x0.w) * (rp.w - x0.w);
+    float ab = 0.f;
+    for (int t = 1; t < T; ++t) {
+      const float4 rc = r[(int64_t)t * P4], xc = x[(int64_t)t * P4];
+      sq += (rc.x - xc.x) * (rc.x - xc.x) + (rc.y - xc.y) * (rc.y - xc.y) + (rc.z - xc.z) * (rc.z - xc.z) +
+            (rc.w - xc.w) * (rc.w - xc.w);
+      ab += fabsf(rc.x - rp.x) + fabsf(rc.y - rp.y) + fabsf(rc.z - rp.z) + fabsf(rc.w - rp.w);
+      rp = rc;
+    }
+    s_sq += (double)sq;
+    s_ab += (double)ab;
+  }
+  const double a = block_sum_256(s_sq, red);
+  const double b2 = block_sum_256(s_ab, red);
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x] = a;
+    partials[2 * blockIdx.x + 1] = b2;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+recon_metrics_finalize_kernel(const double* __restrict__ partials, int nparts, float* __restrict__ out, double B,
+                              double T, double P, double max_val) {
+  __shared__ double red[4];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) {
+    a += partials[2 * i];
+    b += partials[2 * i + 1];
+  }
+  a = block_sum_256(a, red);
+  b = block_sum_256(b, red);
+  if (threadIdx.x == 0) {
+    const float mse = (float)(a / (B * T * P));        // rounded to fp32 first, as F.mse_loss(...).item() is
+    out[0] = mse;
+    out[1] = mse == 0.f ? __builtin_inff() : (float)(10.0 * log10(max_val * max_val / (double)mse));
+    out[2] = T > 1 ? (float)(b / (B * (T - 1) * P)) : __builtin_nanf("");   // mean of no elements
+  }
+}
+
+extern "C" int dvae_recon_metrics_f32(const float* recon, const float* target, float* out, float* ws, int64_t B,
+                                      int64_t T, int64_t P, float max_val, dvae_stream_t stream) {
+  DVAE_REQUIRE(B > 0 && T >= 1 && P > 0 && P % 4 == 0, "recon_metrics: need P%%4==0 (P=%ld)", (long)P);
+  DVAE_REQUIRE(((((uintptr_t)recon) | ((uintptr_t)target)) & 15) == 0, "recon_metrics: clips must be 16-byte aligned");
+  DVAE_REQUIRE(ws != nullptr && ((uintptr_t)ws & 7) == 0, "recon_metrics: workspace must be 8-byte aligned");
+  const int nb = recon_blocks(B, P);
+  hipLaunchKernelGGL(recon_metrics_kernel, dim3(nb), dim3(256), 0, ST(stream), (const float4*)recon,
+                     (const float4*)target, (double*)ws, B * (P / 4), (int)T, P / 4);
+  DVAE_LAUNCH_CHECK("recon_metrics");
+  hipLaunchKernelGGL(recon_metrics_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, nb, out,
+                     (double)B, (double)T, (double)P, (double)max_val);
+  DVAE_LAUNCH_CHECK("recon_metrics_finalize");
+  return 0;
+}
+
 __device__ __forceinline__ float recon_grad_elem(float r, float x, int kind) {
   if (kind == 0) return 2.f * (r - x);
   // F.binary_cross_entropy backward: (r - x) / max((1 - r) * r, 1e-12)

@@ -33,6 +33,7 @@ SIGNATURES = {
     'dvae_split_mean_diff_f32': (I, [P, P, P, L, L, L, P]),
     'dvae_recon_loss_ws_floats': (L, [L, L, L]),
     'dvae_recon_loss_fwd_f32': (I, [P, P, P, P, L, L, L, I, I, P]),
+    'dvae_recon_metrics_f32': (I, [P, P, P, P, L, L, L, F, P]),
     'dvae_recon_loss_bwd_f32': (I, [P, P, P, P, L, L, L, I, F, P]),
     'dvae_reparam_fwd_f32': (I, [P, P, P, P, L, P]),
     'dvae_reparam_bwd_f32': (I, [P, P, P, P, P, L, P]),

@@ -86,6 +86,22 @@ def recon_loss_fwd(recon: Tensor, target: Tensor, kind: int, with_temporal: bool
                                       int(with_temporal), _stream()), 'recon_loss_fwd')
 
 
+def recon_metrics(recon: Tensor, target: Tensor, max_val: float = 1.0, out: Optional[Tensor] = None) -> Tensor:
+    """recon, target [B,T,...] -> device tensor [mse, psnr, temporal consistency of recon] in one pass
+    (evaluation/metrics.py:14-22, :48-50 of the reference); nothing is read back."""
+    _chk(recon, target)
+    if recon.shape != target.shape:
+        raise RuntimeError(f"recon_metrics: shapes differ: {tuple(recon.shape)} vs {tuple(target.shape)}")
+    B, T = recon.shape[:2]
+    P = recon[0, 0].numel()
+    if out is None:
+        out = torch.empty(3, dtype=torch.float32, device=recon.device)
+    ws = workspace(lib.dvae_recon_loss_ws_floats(B, T, P), recon.device)
+    check(lib.dvae_recon_metrics_f32(_p(recon), _p(target), _p(out), _p(ws), B, T, P, float(max_val), _stream()),
+          'recon_metrics')
+    return out
+
+
 def recon_loss_bwd(recon: Tensor, target: Tensor, gscale: Optional[Tensor], kind: int,
                    temporal_weight: float) -> Tensor:
     _chk(recon, target, gscale)

@@ -73,6 +73,14 @@ int dvae_recon_loss_bwd_f32(const float* recon, const float* target, const float
                             int64_t B, int64_t T, int64_t P, int kind, float temporal_weight,
                             dvae_stream_t stream);
 
+/* ---- reconstruction metrics of the evaluation loop in one pass (evaluation/metrics.py:14-22 mse and
+ *      psnr, :48-50 temporal_consistency; called per batch from reconstruction_metrics, :80-83).
+ *      out[0] = mean squared error, out[1] = 10*log10(max_val^2 / out[0]) (+inf when out[0] == 0),
+ *      out[2] = mean |recon[:,1:] - recon[:,:-1]| (NaN when T == 1, like torch's mean of no elements).  recon, target: [B][T][P] with
+ *      P % 4 == 0; ws: dvae_recon_loss_ws_floats(B,T,P) floats, 8-byte aligned. */
+int dvae_recon_metrics_f32(const float* recon, const float* target, float* out, float* ws, int64_t B,
+                           int64_t T, int64_t P, float max_val, dvae_stream_t stream);
+
 /* ---- reparameterisation (models/encoders.py:207-214): z = mu + eps*exp(0.5*logvar), n elements. */
 int dvae_reparam_fwd_f32(const float* mu, const float* logvar, const float* eps, float* z, int64_t n,
                          dvae_stream_t stream);

@@ -311,6 +311,15 @@ def temporal_term(recon: Tensor, target: Tensor) -> Tensor:
     return ((rd - td) ** 2).mean() * rd[0].numel()
 
 
+def recon_metrics(recon: Tensor, target: Tensor, max_val: float = 1.0) -> Tuple[float, float, float]:
+    """(mse, psnr, temporal consistency of recon) as the reference's evaluation loop computes them per
+    batch (evaluation/metrics.py:14-15 mse, :18-22 psnr, :48-50 temporal_consistency)."""
+    m = F.mse_loss(recon, target, reduction='mean').item()
+    p = float('inf') if m == 0 else 10 * np.log10(max_val ** 2 / m)
+    tc = (recon[:, 1:] - recon[:, :-1]).abs().mean().item()
+    return m, float(p), tc
+
+
 def kl_per_dim(mu: Tensor, logvar: Tensor) -> Tensor:
     return -0.5 * (1 + logvar - mu ** 2 - logvar.exp())
 

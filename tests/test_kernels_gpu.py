@@ -4,6 +4,7 @@ Tolerances: fp32 kernels vs an fp64 reference of the same operation; relative L2
 GEMM-shaped kernels (K up to a few thousand), element tolerances written per test.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -693,3 +694,51 @@ def test_permute3_is_exact(ops, dims, perm):
     got = ops.permute3(x, dims, perm)
     assert got.shape == tuple(dims[p] for p in perm)
     assert torch.equal(got, x.permute(*perm).contiguous())
+
+
+# ------------------------------------------------------------------------------- evaluation metrics
+@pytest.mark.parametrize('case', ['small', 'one_frame', 'clip', 'identical', 'half_range'])
+def test_recon_metrics_kernel_matches_reference_values(ops, case):
+    """One-pass mse / psnr / temporal consistency against the values the reference's own functions gave
+    for the same tensors (fixture) and against the fp64 oracle; 1e-6 relative (fp32 inputs, double sums)."""
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'metrics.npz'))
+    recon, target = torch.from_numpy(z[f'{case}/recon']), torch.from_numpy(z[f'{case}/target'])
+    mv = 0.5 if case == 'half_range' else 1.0
+    got = ops.recon_metrics(dev(recon), dev(target), max_val=mv).cpu().double().numpy()
+    want64 = O.recon_metrics(recon.double(), target.double(), max_val=mv)
+    for g, w, w64 in zip(got, z[f'{case}/expect'], want64):
+        for ref_v in (float(w), float(w64)):
+            if np.isnan(ref_v):
+                assert np.isnan(g)
+            elif np.isinf(ref_v):
+                assert g == ref_v
+            else:
+                assert abs(g - ref_v) <= 1e-6 * abs(ref_v), (case, got, z[f'{case}/expect'], want64)
+
+
+def test_evaluation_metrics_module(ops):
+    """evaluation.metrics keeps the reference's function names and dictionary keys; values agree with the
+    oracle on a two-batch loader of an untrained model."""
+    import models
+    from evaluation import metrics as M
+    torch.manual_seed(3)
+    model = models.get_model('baseline', in_channels=1, latent_dim=16, encoder_channels=[8, 16, 16, 32],
+                             decoder_channels=[32, 16, 16, 8], feature_dim=32, sequence_length=4).cuda()
+    g = torch.Generator().manual_seed(4)
+    batches = [(torch.rand(2, 4, 1, 64, 64, generator=g), {}) for _ in range(2)]
+    res = M.reconstruction_metrics(model, batches, torch.device('cuda'))
+    assert set(res) == {'mse', 'psnr', 'ssim', 'temporal_consistency', 'mse_std', 'psnr_std', 'ssim_std'}
+    model.eval()
+    rows = []
+    with torch.no_grad():
+        for v, _ in batches:
+            recon = model(v.cuda())[0].cpu()
+            rows.append(O.recon_metrics(recon.double(), v.double()))
+    rows = np.asarray(rows)
+    assert abs(res['mse'] - rows[:, 0].mean()) <= 1e-6 * rows[:, 0].mean()
+    assert abs(res['psnr'] - rows[:, 1].mean()) <= 1e-6 * abs(rows[:, 1].mean())
+    assert abs(res['temporal_consistency'] - rows[:, 2].mean()) <= 1e-6 * rows[:, 2].mean()
+    assert abs(res['mse_std'] - rows[:, 0].std()) <= 1e-5 * rows[:, 0].mean()
+    v = batches[0][0]
+    assert abs(M.temporal_consistency(v.cuda()) - O.recon_metrics(v.double(), v.double())[2]) <= 1e-6
+    assert M.psnr(v.cuda(), v.cuda()) == float('inf')

@@ -137,3 +137,26 @@ def test_generator_matches_reference():
         np.testing.assert_array_equal(pos[0], np.array(item['initial_positions']))
         np.testing.assert_array_equal(vel[-1], np.array(item['last_velocities']))
         np.testing.assert_array_equal(pos[-1], np.array(item['last_positions']))
+
+
+METRIC_CASES = ['small', 'one_frame', 'clip', 'identical', 'half_range']
+
+
+def _close_or_same_special(got, want, rtol):
+    if np.isnan(want):
+        return np.isnan(got)
+    if np.isinf(want):
+        return got == want
+    return abs(got - want) <= rtol * max(abs(want), 1e-30)
+
+
+@pytest.mark.parametrize('case', METRIC_CASES)
+def test_recon_metrics_match_reference(case):
+    """mse / psnr / temporal consistency against the values the reference's functions returned
+    (tests/golden/make_golden_metrics.py), the special values included (inf at zero error, NaN for a
+    single frame)."""
+    z = np.load(os.path.join(GOLDEN, "metrics.npz"))
+    recon, target = torch.from_numpy(z[f'{case}/recon']), torch.from_numpy(z[f'{case}/target'])
+    got = O.recon_metrics(recon, target, max_val=0.5 if case == 'half_range' else 1.0)
+    for g, w in zip(got, z[f'{case}/expect']):
+        assert _close_or_same_special(g, float(w), 1e-12), (case, got, z[f'{case}/expect'])
