@@ -10,10 +10,12 @@ What differs underneath:
   * with torch.distributed initialised (one process per GPU) gradients are averaged across ranks by
     bucketed all-reduce overlapped with backward (hipvae.parallel.GradSync); rank 0 logs and saves.
 """
+import copy
 import json
 import math
 import os
 import sys
+import threading
 import time
 from typing import Dict, Optional, Tuple
 
@@ -63,6 +65,21 @@ def beta_for_epoch(t, epoch: int) -> float:
     return t.beta_vae
 
 
+def _map_tensors(o, fn):
+    """o with fn applied to every tensor inside dicts, lists and tuples; containers keep their type and a
+    state_dict keeps its _metadata attribute."""
+    if torch.is_tensor(o):
+        return fn(o)
+    if isinstance(o, dict):
+        out = type(o)((k, _map_tensors(v, fn)) for k, v in o.items())
+        if hasattr(o, '_metadata'):
+            out._metadata = copy.deepcopy(o._metadata)
+        return out
+    if isinstance(o, (list, tuple)):
+        return type(o)(_map_tensors(v, fn) for v in o)
+    return o
+
+
 class Trainer:
 
     def __init__(self, model: nn.Module, config: ExperimentConfig, train_loader, val_loader,
@@ -103,6 +120,8 @@ class Trainer:
             use_graph = os.environ.get('DVAE_HIPGRAPH', '0') == '1'
         self.use_graph = bool(use_graph)
         self._graphs = {}                 # (batch shape, beta) -> GraphedTrainStep
+        self.async_checkpoint = os.environ.get('DVAE_ASYNC_CKPT', '1') != '0'
+        self._ckpt_thread, self._ckpt_stream, self._ckpt_keep, self._ckpt_error = None, None, None, None
 
         self.checkpoint_dir = os.path.join(t.checkpoint_dir, config.name)
         self.results_dir = os.path.join(t.results_dir, config.name)
@@ -256,24 +275,86 @@ class Trainer:
 
     # ------------------------------------------------------------------ checkpoints
     def save_checkpoint(self, filename: str = 'checkpoint.pt'):
+        """The reference's checkpoint dictionary (training/trainer.py:261-276), written off the training
+        path: device tensors are cloned on the compute stream (a fraction of a millisecond), the clones
+        travel to pinned host memory on a side stream, and a writer thread serialises the file once they
+        have arrived, while training goes on.  One write is in flight at a time; load_checkpoint() and the
+        end of train() wait for it.  async_checkpoint=False writes before returning."""
         if self.rank != 0:
             return
+        self.wait_for_checkpoint()
         ckpt = {
             'epoch': self.current_epoch,
             'global_step': self.global_step,
             'model_state_dict': self.model.state_dict(),
             'optimizer_state_dict': self.optimizer.state_dict(),
             'best_val_loss': self.best_val_loss,
-            'history': self.history,
+            'history': copy.deepcopy(self.history),
             'config': self.config.to_dict(),
         }
         if self.scheduler is not None:
-            ckpt['scheduler_state_dict'] = self.scheduler.state_dict()
+            ckpt['scheduler_state_dict'] = copy.deepcopy(self.scheduler.state_dict())
         path = os.path.join(self.checkpoint_dir, filename)
-        torch.save(ckpt, path)
-        print(f"Saved checkpoint to {path}")
+        if not self.async_checkpoint:
+            torch.save(ckpt, path)
+            print(f"Saved checkpoint to {path}")
+            return
+        ckpt, arrived = self._to_host_async(ckpt)
+
+        def write():
+            try:
+                arrived.synchronize()
+                tmp = path + '.tmp'
+                torch.save(ckpt, tmp)
+                os.replace(tmp, path)
+                print(f"Saved checkpoint to {path}")
+            except BaseException as e:                      # surfaced by wait_for_checkpoint()
+                self._ckpt_error = e
+        self._ckpt_thread = threading.Thread(target=write, name='checkpoint-writer')
+        self._ckpt_thread.start()
+
+    def _to_host_async(self, obj):
+        """obj with every GPU tensor replaced by a pinned host copy that is still arriving, and the event
+        that marks the arrival of all of them."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._ckpt_stream is None:
+            self._ckpt_stream = torch.cuda.Stream(device=self.device)
+        side = self._ckpt_stream
+        clones = []
+
+        def snap(t):                                         # compute stream: a consistent copy, now
+            c = t.detach().clone()
+            if c.is_cuda:
+                clones.append(c)
+            return c
+        snapped = _map_tensors(obj, snap)
+        side.wait_stream(cur)
+        hosts = {}
+        with torch.cuda.stream(side):
+            for c in clones:
+                h = torch.empty(c.shape, dtype=c.dtype, pin_memory=True)
+                h.copy_(c, non_blocking=True)
+                hosts[id(c)] = h
+        arrived = torch.cuda.Event()
+        arrived.record(side)
+
+        out = _map_tensors(snapped, lambda t: hosts.get(id(t), t))
+        self._ckpt_keep = clones                             # alive until the copies have been waited for
+        return out, arrived
+
+    def wait_for_checkpoint(self):
+        """Block until the checkpoint being written (if any) is on disk; re-raises a failed write."""
+        th = self._ckpt_thread
+        if th is not None:
+            th.join()
+            self._ckpt_thread = None
+            self._ckpt_keep = None
+        if self._ckpt_error is not None:
+            e, self._ckpt_error = self._ckpt_error, None
+            raise RuntimeError("writing the previous checkpoint failed") from e
 
     def load_checkpoint(self, filename: str = 'checkpoint.pt'):
+        self.wait_for_checkpoint()
         path = os.path.join(self.checkpoint_dir, filename)
         if not os.path.exists(path):
             print(f"No checkpoint found at {path}")
@@ -360,6 +441,7 @@ class Trainer:
                 self.visualize_reconstructions()
                 self.visualize_samples()
         self.save_checkpoint('final_model.pt')
+        self.wait_for_checkpoint()
         if self.rank == 0:
             with open(os.path.join(self.results_dir, 'training_history.json'), 'w') as f:
                 json.dump(self.history, f, indent=2)

@@ -329,3 +329,61 @@ def test_cli_end_to_end(tmp_path, flags):
     assert hist['train_recon'][1] < hist['train_recon'][0]
     files = sorted(os.listdir(tmp_path / 'ck' / 'cli_run'))
     assert 'final_model.pt' in files and 'best_model.pt' in files and 'config.json' in files
+
+
+def test_async_checkpoint_is_a_consistent_snapshot(tmp_path):
+    """save_checkpoint() returns before the file is written; what lands on disk is the state at the call,
+    even though parameters and optimiser state are overwritten right afterwards, and equals what the
+    blocking writer produces."""
+    from training.config import ExperimentConfig
+    from training.trainer import create_trainer
+    cfg = ExperimentConfig(name='ckpt')
+    cfg.model.model_type = 'baseline'
+    cfg.model.latent_dim, cfg.model.feature_dim = 16, 32
+    cfg.model.encoder_channels, cfg.model.decoder_channels = [8, 16, 16, 32], [32, 16, 16, 8]
+    cfg.model.sequence_length = cfg.data.sequence_length = 4
+    cfg.training.device = 'cuda'
+    cfg.training.checkpoint_dir, cfg.training.results_dir = str(tmp_path / 'ck'), str(tmp_path / 'res')
+    clips = [(synthetic_clips(4, 4, 7), [{}] * 4)]
+    torch.manual_seed(11)
+    tr = create_trainer(cfg, clips, clips)
+    tr.train_epoch()                                             # some optimiser state to save
+    want = {k: v.detach().clone() for k, v in tr.model.state_dict().items()}
+    want_opt = [tr.optimizer.state_dict()['state'][i]['exp_avg'].detach().clone() for i in range(3)]
+    saved_p = [p.detach().clone() for p in tr.model.parameters()]
+    saved_m = [st['exp_avg'].detach().clone() for st in tr.optimizer.state.values()]
+    assert tr.async_checkpoint
+    tr.save_checkpoint('a.pt')
+    with torch.no_grad():                                        # training goes on: everything changes
+        for p in tr.model.parameters():
+            p.add_(1.0)
+        for st in tr.optimizer.state.values():
+            st['exp_avg'].mul_(3.0)
+    tr.wait_for_checkpoint()
+    ck_dir = os.path.join(cfg.training.checkpoint_dir, cfg.name)
+    assert sorted(f for f in os.listdir(ck_dir) if f.endswith('.pt') or f.endswith('.tmp')) == ['a.pt']
+    a = torch.load(os.path.join(ck_dir, 'a.pt'), weights_only=False)
+    for k, v in want.items():
+        assert torch.equal(a['model_state_dict'][k].cpu(), v.cpu()), k
+    for i, v in enumerate(want_opt):
+        assert torch.equal(a['optimizer_state_dict']['state'][i]['exp_avg'].cpu(), v.cpu())
+    assert getattr(a['model_state_dict'], '_metadata', None) is not None
+    # the blocking writer stores the same dictionary
+    with torch.no_grad():
+        for p, v in zip(tr.model.parameters(), saved_p):
+            p.copy_(v)
+        for st, v in zip(tr.optimizer.state.values(), saved_m):
+            st['exp_avg'].copy_(v)
+    tr.async_checkpoint = False
+    tr.save_checkpoint('b.pt')
+    b = torch.load(os.path.join(ck_dir, 'b.pt'), weights_only=False)
+    assert sorted(a.keys()) == sorted(b.keys())
+    for k in want:
+        assert torch.equal(a['model_state_dict'][k].cpu(), b['model_state_dict'][k].cpu()), k
+    assert a['history'] == b['history'] and a['config'] == b['config'] and a['epoch'] == b['epoch']
+    # and a failed write is reported, not swallowed
+    tr.async_checkpoint = True
+    tr.checkpoint_dir = str(tmp_path / 'does' / 'not' / 'exist')
+    tr.save_checkpoint('c.pt')
+    with pytest.raises(RuntimeError, match='checkpoint failed'):
+        tr.wait_for_checkpoint()
