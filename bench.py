@@ -503,6 +503,14 @@ def main():
                                       'loss': round(float(out['total_loss'].item()), 3),
                                       'workload': 'same training step with bf16 MFMA operands (fp32 accumulate, '
                                                   'fp32 tensors); not the headline value'}
+            ops.set_precision('fp32_split')
+            el, out = measure(make_train_step(), args.steps, args.warmup)
+            result['fp32_split_variant'] = {
+                'value': round(world * B * args.steps / el, 2), 'unit': 'clips/s',
+                'ms_per_step': round(el / args.steps * 1e3, 3), 'loss': round(float(out['total_loss'].item()), 3),
+                'workload': 'same training step with the Linear-layer GEMMs forming each fp32 product from six '
+                            'bf16 MFMA products of a three-term operand split (fp32-level error); not the headline '
+                            'value'}
             ops.set_precision('fp32')
     if use_dp:
         dist.barrier()

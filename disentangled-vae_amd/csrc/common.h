@@ -20,6 +20,7 @@ void dvae_set_error(const char* fmt, ...);
 // operand precision of the MFMA GEMM / convolution kernels (process-wide switch)
 #define DVAE_PRECISION_F32 0
 #define DVAE_PRECISION_BF16 1
+#define DVAE_PRECISION_F32_SPLIT 2
 int dvae_mfma_precision();
 
 #define DVAE_REQUIRE(cond, ...)                 \

@@ -1342,7 +1342,7 @@ extern "C" int dvae_conv4s2_dgrad_bnstat_f32(const float* x, const float* wp, fl
 
 extern "C" int dvae_conv4s2_bnin_supported(int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
   (void)H;
-  return dvae_mfma_precision() == DVAE_PRECISION_F32 && Cin == 32 && Cout == 64 && W == 32;
+  return dvae_mfma_precision() != DVAE_PRECISION_BF16 && Cin == 32 && Cout == 64 && W == 32;
 }
 
 extern "C" int dvae_conv4s2_dgrad_bnstat_bnin_f32(const float* du_in, const float* in_y, const float* in_scale,
@@ -1369,7 +1369,7 @@ extern "C" int dvae_deconv4s2_dgrad_bnstat_f32(const float* x, const float* wp, 
 
 extern "C" int dvae_deconv4s2_bnin_supported(int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
   (void)H;
-  return dvae_mfma_precision() == DVAE_PRECISION_F32 && Cin == 32 && Cout == 16 && (W == 16 || W == 32);
+  return dvae_mfma_precision() != DVAE_PRECISION_BF16 && Cin == 32 && Cout == 16 && (W == 16 || W == 32);
 }
 
 extern "C" int dvae_deconv4s2_dgrad_bnstat_bnin_f32(const float* du_in, const float* in_y, const float* in_scale,
@@ -2157,7 +2157,7 @@ static bool wgrad_rows_shape(int64_t C1, int64_t C2, int64_t Ws) {
 
 static WgradPlan wgrad_plan(int64_t Mtot, int64_t Ws, int64_t C1, int64_t C2, int64_t Hs = 0) {
   WgradPlan p;
-  if (C1 == 256 && C2 == 128 && Ws == 4 && Hs == 4 && Mtot >= 16 * 32 && dvae_mfma_precision() == DVAE_PRECISION_F32) {
+  if (C1 == 256 && C2 == 128 && Ws == 4 && Hs == 4 && Mtot >= 16 * 32 && dvae_mfma_precision() != DVAE_PRECISION_BF16) {
     // sixteen workgroups (filter taps) per slab; 16 x 32 = two workgroups per compute unit
     p.bm = -3;
     p.tm = p.tn = 1;
@@ -2175,7 +2175,7 @@ static WgradPlan wgrad_plan(int64_t Mtot, int64_t Ws, int64_t C1, int64_t C2, in
     p.ktiles_per_split = 0;
     return p;
   }
-  if (C1 == 128 && C2 == 64 && Ws == 8 && Mtot >= 16 && dvae_mfma_precision() == DVAE_PRECISION_F32) {
+  if (C1 == 128 && C2 == 64 && Ws == 8 && Mtot >= 16 && dvae_mfma_precision() != DVAE_PRECISION_BF16) {
     // four workgroups (filter rows) per slab; 4 x 128 = two workgroups per compute unit
     p.bm = -2;
     p.tm = p.tn = 1;
@@ -2184,7 +2184,7 @@ static WgradPlan wgrad_plan(int64_t Mtot, int64_t Ws, int64_t C1, int64_t C2, in
     p.ktiles_per_split = 0;
     return p;
   }
-  if (wgrad_rows_shape(C1, C2, Ws) && dvae_mfma_precision() == DVAE_PRECISION_F32) {
+  if (wgrad_rows_shape(C1, C2, Ws) && dvae_mfma_precision() != DVAE_PRECISION_BF16) {
     // one slab per workgroup; as many workgroups as are resident at once
     p.bm = -1;
     p.tm = p.tn = 1;

@@ -22,7 +22,8 @@ static int g_mfma_precision = DVAE_PRECISION_F32;
 int dvae_mfma_precision() { return g_mfma_precision; }
 extern "C" int dvae_get_mfma_precision(void) { return g_mfma_precision; }
 extern "C" int dvae_set_mfma_precision(int precision) {
-  DVAE_REQUIRE(precision == DVAE_PRECISION_F32 || precision == DVAE_PRECISION_BF16,
+  DVAE_REQUIRE(precision == DVAE_PRECISION_F32 || precision == DVAE_PRECISION_BF16 ||
+                   precision == DVAE_PRECISION_F32_SPLIT,
                "set_mfma_precision: unknown precision %d", precision);
   g_mfma_precision = precision;
   return 0;

@@ -20,7 +20,7 @@ struct GemmArgs {
   int tm0;      // first row of tiles of this launch (a product may be split over two launches)
 };
 
-template <class T, int KIND, bool BF>
+template <class T, int KIND, int BF>      // BF: PREC_F32 / PREC_BF16 / PREC_SPLIT
 __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * Core<T, BF>::STAGE];
   const int64_t m0 = (int64_t)(blockIdx.y + g.tm0) * T::BM, n0 = (int64_t)blockIdx.x * T::BN;
@@ -38,12 +38,14 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
     gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
   } else if (KIND == G_NN) {
     KCLoader<T::A_V4> la(g.A, g.lda, g.M, g.K, m0);
-    RCLoader<T::B_V4, T::BN, BF> lb(g.B, g.ldb, g.N, g.K, n0);
-    gemm_mainloop_ahead2<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
+    RCLoader<T::B_V4, T::BN, Core<T, BF>::KADJ> lb(g.B, g.ldb, g.N, g.K, n0);
+    if (BF == PREC_F32) gemm_mainloop_ahead2<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
+    else gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
   } else {
-    RCLoader<T::A_V4, T::BM, BF> la(g.A, g.lda, g.M, g.K, m0);
-    RCLoader<T::B_V4, T::BN, BF> lb(g.B, g.ldb, g.N, g.K, n0);
-    gemm_mainloop_ahead2<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
+    RCLoader<T::A_V4, T::BM, Core<T, BF>::KADJ> la(g.A, g.lda, g.M, g.K, m0);
+    RCLoader<T::B_V4, T::BN, Core<T, BF>::KADJ> lb(g.B, g.ldb, g.N, g.K, n0);
+    if (BF == PREC_F32) gemm_mainloop_ahead2<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
+    else gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
   }
 
   if (g.slab) {
@@ -262,7 +264,18 @@ static int launch_gemm(const char* name, GemmArgs g, float* ws, hipStream_t stre
   }
   const dim3 grid((unsigned)p.tn, (unsigned)p.tm, (unsigned)p.split);
   constexpr bool AKC = KIND != G_TN, BKC = KIND == G_NT;
-  const bool bf = dvae_mfma_precision() == DVAE_PRECISION_BF16;
+  const int prec = dvae_mfma_precision();
+  typedef Tile<32, 128, 1, 4, AKC, BKC> Skinny;
+  typedef Tile<128, 128, 2, 2, AKC, BKC> Big;
+#define GEMM_LAUNCH(TILE, KIND_, GRID)                                                                   \
+  {                                                                                                      \
+    if (prec == DVAE_PRECISION_BF16)                                                                     \
+      hipLaunchKernelGGL((gemm_kernel<TILE, KIND_, PREC_BF16>), GRID, dim3(256), 0, stream, g);          \
+    else if (prec == DVAE_PRECISION_F32_SPLIT)                                                           \
+      hipLaunchKernelGGL((gemm_kernel<TILE, KIND_, PREC_SPLIT>), GRID, dim3(256), 0, stream, g);         \
+    else                                                                                                 \
+      hipLaunchKernelGGL((gemm_kernel<TILE, KIND_, PREC_F32>), GRID, dim3(256), 0, stream, g);           \
+  }
   g.tm0 = 0;
   // tiles that fill the 512 workgroup slots a whole number of times and then leave between a fifth and
   // seven tenths of a round: the remaining rows of tiles go to a second launch with 64-wide tiles,
@@ -275,22 +288,16 @@ static int launch_gemm(const char* name, GemmArgs g, float* ws, hipStream_t stre
       typedef Tile<128, 64, 4, 1, true, true> Narrow;
       const dim3 head((unsigned)p.tn, (unsigned)head_tm, 1);
       const dim3 tail((unsigned)ceil_div64(g.N, 64), (unsigned)(p.tm - head_tm), 1);
-      if (bf) hipLaunchKernelGGL((gemm_kernel<Wide, G_NT, true>), head, dim3(256), 0, stream, g);
-      else hipLaunchKernelGGL((gemm_kernel<Wide, G_NT, false>), head, dim3(256), 0, stream, g);
+      GEMM_LAUNCH(Wide, G_NT, head)
       g.tm0 = (int)head_tm;
-      if (bf) hipLaunchKernelGGL((gemm_kernel<Narrow, G_NT, true>), tail, dim3(256), 0, stream, g);
-      else hipLaunchKernelGGL((gemm_kernel<Narrow, G_NT, false>), tail, dim3(256), 0, stream, g);
+      GEMM_LAUNCH(Narrow, G_NT, tail)
       DVAE_LAUNCH_CHECK(name);
       return 0;
     }
   }
-  if (p.small_m) {
-    if (bf) hipLaunchKernelGGL((gemm_kernel<Tile<32, 128, 1, 4, AKC, BKC>, KIND, true>), grid, dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((gemm_kernel<Tile<32, 128, 1, 4, AKC, BKC>, KIND, false>), grid, dim3(256), 0, stream, g);
-  } else {
-    if (bf) hipLaunchKernelGGL((gemm_kernel<Tile<128, 128, 2, 2, AKC, BKC>, KIND, true>), grid, dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((gemm_kernel<Tile<128, 128, 2, 2, AKC, BKC>, KIND, false>), grid, dim3(256), 0, stream, g);
-  }
+  if (p.small_m) GEMM_LAUNCH(Skinny, KIND, grid)
+  else GEMM_LAUNCH(Big, KIND, grid)
+#undef GEMM_LAUNCH
   DVAE_LAUNCH_CHECK(name);
   if (p.split > 1) {
     // four columns per thread when rows are whole float4s in the slab (16-byte aligned with its M*N

@@ -236,12 +236,131 @@ __device__ __forceinline__ void mma_stage_bf16(const uint32_t* __restrict__ As, 
   }
 }
 
-// The two operand precisions behind one interface.  STAGE is in 4-byte units.
-template <class T, bool BF>
+// ---- fp32 products from bf16 MFMAs (PREC_SPLIT) -------------------------------------------------
+// An fp32 value is split into three bf16 terms hi + mid + lo (each the nearest bf16 of what the terms
+// before it leave over; the first two remainders are exact in fp32, the last rounding is below 2^-25
+// of the value), so a product a*b is the sum of nine bf16 x bf16 products, each exact in the fp32
+// accumulator.  The six largest are formed (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi); the three
+// dropped ones (mid*lo, lo*mid, lo*lo) are below 2^-24 of |a*b|, the size of fp32's own rounding.
+// Operands stay fp32 in memory and in LDS (the fp32 images and loaders are used unchanged); a lane
+// splits its fragments after reading them, eight k per operand row for v_mfma_f32_32x32x16_bf16.
+// one pair of fp32 values -> the packed bf16 pairs of its three terms
+__device__ __forceinline__ float bf_lo_as_float(uint32_t pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float bf_hi_as_float(uint32_t pk) { return __uint_as_float(pk & 0xffff0000u); }
+
+__device__ __forceinline__ void split_pair(float a0, float a1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  const f32x2 a = {a0, a1};
+  const uint32_t h = pack_bf16(a[0], a[1]);
+  const f32x2 r = a - (f32x2){bf_lo_as_float(h), bf_hi_as_float(h)};         // exact
+  const uint32_t m = pack_bf16(r[0], r[1]);
+  const f32x2 t = r - (f32x2){bf_lo_as_float(m), bf_hi_as_float(m)};         // exact
+  hi = h;
+  mid = m;
+  lo = pack_bf16(t[0], t[1]);
+}
+
+// Raw fp32 fragments of the 16-deep group g of a staged K step: eight k per operand row and lane.
+// Which eight k of a group a lane holds is free as long as A and B agree: lane half h takes
+// k = 8q + 4h .. +3 for the group's two q.  Fragment f < TM is A's row block f, the others are B's.
+template <class T>
+__device__ __forceinline__ void load_group(const float* __restrict__ As, const float* __restrict__ Bs, int g, int wm,
+                                           int wn, int l31, int h, float (&v)[T::TM + T::TN][8]) {
+#pragma unroll
+  for (int f = 0; f < T::TM + T::TN; ++f) {
+    const bool isa = f < T::TM;
+    const int row = ((isa ? wm * T::TM + f : wn * T::TN + (f - T::TM))) * 32 + l31;
+    const float* S = isa ? As : Bs;
+    const int ld = isa ? T::ALD : T::BLD;
+    const bool kc = isa ? T::AKC : T::BKC;
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const int q = 2 * g + qq;
+      if (kc) {
+        const float4 t = *reinterpret_cast<const float4*>(S + row * ld + 8 * q + 4 * h);
+        v[f][4 * qq] = t.x; v[f][4 * qq + 1] = t.y; v[f][4 * qq + 2] = t.z; v[f][4 * qq + 3] = t.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[f][4 * qq + e] = S[(8 * q + 4 * h + e) * ld + row];
+      }
+    }
+  }
+}
+
+// split terms of a group's fragments: w[term][fragment][pair], term 0 = hi, 1 = mid, 2 = lo
+template <int NF>
+struct SplitFrags {
+  uint32_t w[3][NF][4];
+  __device__ __forceinline__ bf16x8 get(int term, int f) const {
+    bf16x8 o;
+    __builtin_memcpy(&o, w[term][f], 16);
+    return o;
+  }
+};
+
+// One staged K step (32 deep, fp32 images) as two 16-deep bf16 MFMA groups, six products each, smallest
+// terms first.  A wave issues in program order and an MFMA holds it for the time of eight vector
+// instructions, so the second group's splitting is written between the first group's MFMAs, one pair of
+// values per MFMA, with scheduling fences that keep the compiler from regrouping them; only the first
+// group's split runs with the matrix pipe idle.
+template <class T>
+__device__ __forceinline__ void mma_stage_split(const float* __restrict__ As, const float* __restrict__ Bs,
+                                                f32x16 (&acc)[T::TM][T::TN], int wm, int wn, int lane) {
+  static_assert(T::BK == 32, "two 16-deep groups per K step");
+  constexpr int NF = T::TM + T::TN, NM = 6 * T::TM * T::TN, NT = 4 * NF;
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+  const int l31 = lane & 31, h = lane >> 5;
+  float v[NF][8];
+  SplitFrags<NF> s0, s1;
+  load_group<T>(As, Bs, 0, wm, wn, l31, h, v);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    split_pair(v[t / 4][2 * (t % 4)], v[t / 4][2 * (t % 4) + 1], s0.w[0][t / 4][t % 4], s0.w[1][t / 4][t % 4],
+               s0.w[2][t / 4][t % 4]);
+  load_group<T>(As, Bs, 1, wm, wn, l31, h, v);
+  __builtin_amdgcn_sched_barrier(0);
+  constexpr int PER = (NT + NM - 1) / NM;          // pairs to split per MFMA
+#pragma unroll
+  for (int n = 0; n < NM; ++n) {
+    const int ty = n / (T::TM * T::TN), i = (n % (T::TM * T::TN)) / T::TN, j = n % T::TN;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s0.get(PA[ty], i), s0.get(PB[ty], T::TM + j), acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int t = n * PER + u;
+      if (t < NT)
+        split_pair(v[t / 4][2 * (t % 4)], v[t / 4][2 * (t % 4) + 1], s1.w[0][t / 4][t % 4], s1.w[1][t / 4][t % 4],
+                   s1.w[2][t / 4][t % 4]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int n = 0; n < NM; ++n) {
+    const int ty = n / (T::TM * T::TN), i = (n % (T::TM * T::TN)) / T::TN, j = n % T::TN;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s1.get(PA[ty], i), s1.get(PB[ty], T::TM + j), acc[i][j], 0, 0, 0);
+  }
+}
+
+// The operand precisions behind one interface.  STAGE is in 4-byte units.
+#define PREC_F32 0
+#define PREC_BF16 1
+#define PREC_SPLIT 2
+template <class T, int PREC>
 struct Core;
 
 template <class T>
-struct Core<T, false> {
+struct Core<T, PREC_SPLIT> {
+  static constexpr int STAGE = T::STAGE_FLOATS;
+  static constexpr bool KADJ = false;
+  static __device__ __forceinline__ void store_a(float* st, const f32x4 (&r)[T::A_V4]) { store_a_tile<T>(st, r); }
+  static __device__ __forceinline__ void store_b(float* st, const f32x4 (&r)[T::B_V4]) {
+    store_b_tile<T>(st + T::A_FLOATS, r);
+  }
+  static __device__ __forceinline__ void mma(const float* st, f32x16 (&acc)[T::TM][T::TN], int wm, int wn, int lane) {
+    mma_stage_split<T>(st, st + T::A_FLOATS, acc, wm, wn, lane);
+  }
+};
+
+template <class T>
+struct Core<T, PREC_F32> {
   static constexpr int STAGE = T::STAGE_FLOATS;
   static constexpr bool KADJ = false;
   static __device__ __forceinline__ void store_a(float* st, const f32x4 (&r)[T::A_V4]) { store_a_tile<T>(st, r); }
@@ -254,7 +373,7 @@ struct Core<T, false> {
 };
 
 template <class T>
-struct Core<T, true> {
+struct Core<T, PREC_BF16> {
   static constexpr int A_DW = T::BM * BF_LD, B_DW = T::BN * BF_LD;
   static constexpr int STAGE = A_DW + B_DW;
   static constexpr bool KADJ = true;
@@ -276,7 +395,7 @@ struct Core<T, true> {
 //   void finish(float4 (&regs)[V4])          load-time transform and zero mask, applied just before
 //                                            the registers go to LDS
 // so the loads of tile kt+1 stay in flight for the whole multiply of tile kt.
-template <class T, bool BF, class LA, class LB>
+template <class T, int BF, class LA, class LB>
 __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int kt_begin, int kt_end, float* smem,
                                               f32x16 (&acc)[T::TM][T::TN]) {
   typedef Core<T, BF> C;
@@ -314,7 +433,7 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int kt_begin, int 
 // The same loop with the loads issued two K tiles ahead (two register sets): for tiles whose multiply
 // phase (16-32 MFMAs per wave) is shorter than the memory latency.  Loaders additionally provide
 //   Tag tag() / void set_tag(Tag)    the per-issue state finish() depends on
-template <class T, bool BF, class LA, class LB>
+template <class T, int BF, class LA, class LB>
 __device__ __forceinline__ void gemm_mainloop_ahead2(LA& la, LB& lb, int kt_begin, int kt_end, float* smem,
                                                      f32x16 (&acc)[T::TM][T::TN]) {
   typedef Core<T, BF> C;

@@ -167,19 +167,22 @@ def indep_bwd(zc, zm, ws, gscale, coef: float):
 
 
 # ---------------------------------------------------------------------------- BatchNorm glue
-PRECISIONS = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
+PRECISIONS = {'fp32': 0, 'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1, 'fp32_split': 2}
 
 
 def set_precision(name: str) -> None:
-    """Operand precision of the MFMA GEMM / convolution kernels: 'fp32' (default, exact products) or
-    'bf16' (operands rounded to bf16 when staged into LDS, fp32 accumulation, fp32 tensors)."""
+    """Operand precision of the MFMA GEMM / convolution kernels: 'fp32' (default, exact products on the
+    fp32 matrix instruction), 'bf16' (operands rounded to bf16 when staged into LDS, fp32 accumulation,
+    fp32 tensors) or 'fp32_split' (Linear-layer GEMMs form each fp32 product from six bf16 x bf16
+    products of a three-term split, fp32 accumulation; everything else as in 'fp32')."""
     if name not in PRECISIONS:
-        raise ValueError(f"Unknown precision: {name}. Choose from ['fp32', 'bf16']")
+        raise ValueError(f"Unknown precision: {name}. Choose from {sorted(PRECISIONS)}")
     check(lib.dvae_set_mfma_precision(PRECISIONS[name]), 'set_mfma_precision')
 
 
 def get_precision() -> str:
-    return 'bf16' if lib.dvae_get_mfma_precision() == 1 else 'fp32'
+    code = lib.dvae_get_mfma_precision()
+    return {0: 'fp32', 1: 'bf16', 2: 'fp32_split'}[code]
 
 
 def bn_finalize(partials: Tensor, nparts: int, M: int, gamma, beta, running_mean, running_var, nbt,

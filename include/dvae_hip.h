@@ -38,10 +38,14 @@ const char* dvae_last_error(void);
  *      F32: v_mfma_f32_32x32x2_f32, every product exact (the default; what the 1e-4 parity contract
  *      is stated for).  BF16: tensors stay fp32 in memory, operands are rounded to bf16 (nearest
  *      even) as they are staged into LDS and multiplied by v_mfma_f32_32x32x16_bf16 with fp32
- *      accumulation.  The reference has one precision (fp32, torch defaults); this switch has no
- *      counterpart there. */
+ *      accumulation.  F32_SPLIT (the Linear-layer GEMMs only; every other kernel runs as in F32):
+ *      each fp32 operand is split into three bf16 terms and the six largest of the nine cross
+ *      products are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 -- the dropped terms are below
+ *      2^-24 of the product, fp32's own rounding -- at 6/16 of the fp32 matrix time.  The reference
+ *      has one precision (fp32, torch defaults); this switch has no counterpart there. */
 #define DVAE_PRECISION_F32 0
 #define DVAE_PRECISION_BF16 1
+#define DVAE_PRECISION_F32_SPLIT 2
 int dvae_set_mfma_precision(int precision);
 int dvae_get_mfma_precision(void);
 

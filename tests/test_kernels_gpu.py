@@ -165,6 +165,31 @@ def test_gemm_nn_tn(ops, M, N, K):
         assert rel_err(out, base + at.t() @ b) < 2e-6
 
 
+@pytest.mark.parametrize('M,N,K', GEMM_SHAPES + [(512, 384, 1024)])
+def test_gemm_split_precision_is_fp32_accurate(ops, M, N, K):
+    """'fp32_split' forms every fp32 product from six bf16 x bf16 products of a three-term split: its error
+    against an fp64 product stays at the fp32-MFMA kernels' level (same bound as their tests, and no more
+    than 1.5x what the fp32 mode gives on the same operands), wide dynamic range included."""
+    g = torch.Generator().manual_seed(21)
+    scale = torch.exp2(torch.randint(-20, 20, (M, 1), generator=g).float())     # rows 2^-20 .. 2^20 apart
+    a = (torch.randn(M, K, generator=g) * scale).float()
+    b, bias = rnd(N, K, seed=23).float(), rnd(N, seed=24).float()
+    ref = O.leaky_relu(a.double() @ b.double().t() + bias.double())
+    e32 = rel_err(ops.gemm_nt(dev(a), dev(b), dev(bias), ops.ACT_LRELU), ref)
+    ops.set_precision('fp32_split')
+    try:
+        assert ops.get_precision() == 'fp32_split'
+        es = rel_err(ops.gemm_nt(dev(a), dev(b), dev(bias), ops.ACT_LRELU), ref)
+        bt = rnd(K, N, seed=25).float()
+        e_nn = rel_err(ops.gemm_nn(dev(a), dev(bt)), a.double() @ bt.double())
+        c = rnd(M, N, seed=26).float()
+        e_tn = rel_err(ops.gemm_tn(dev(a), dev(c)), a.double().t() @ c.double()) if K % 4 == 0 and N % 4 == 0 else 0.0
+    finally:
+        ops.set_precision('fp32')
+    assert es < 2e-6 and es <= 1.5 * e32 + 1e-8, (es, e32)
+    assert e_nn < 2e-6 and e_tn < 2e-6, (e_nn, e_tn)
+
+
 def test_gemm_strided_views(ops):
     # operands that are column slices of wider matrices (row stride != width)
     big = dev(rnd(40, 96, seed=17))

@@ -1,7 +1,7 @@
 """Micro-benchmark of the Linear-layer GEMMs on the shapes of the 20x64x64 DisentangledVAE at batch 256,
 one line per (kind, shape).
 
-usage: python tools/bench_gemm.py [--reps 20] [--precision fp32|bf16]
+usage: python tools/bench_gemm.py [--reps 20] [--precision fp32|bf16|fp32_split] [--error]
 """
 import argparse
 import os
@@ -31,6 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--precision', default='fp32')
+    ap.add_argument('--error', action='store_true', help='also print the relative L2 error against an fp64 product')
     a = ap.parse_args()
     ops.set_precision(a.precision)
     dev = 'cuda'
@@ -47,7 +48,14 @@ def main():
                          ('nn  dx = dy w     ', lambda: ops.gemm_nn(dy, w)),
                          ('tn  dw = dy^T x   ', lambda: ops.gemm_tn(dy, x))):
             t = timeit(fn, a.reps)
-            print(f'{name} M={M:5d} K={K:5d} N={N:5d}  {t:8.1f} us  {fl / t / 1e6:7.1f} TFLOP/s', flush=True)
+            err = ''
+            if a.error:
+                x64, w64, dy64 = x.double(), w.double(), dy.double()
+                want = {'nt': lambda: torch.nn.functional.leaky_relu(x64 @ w64.t() + b.double(), 0.2),
+                        'nn': lambda: dy64 @ w64, 'tn': lambda: dy64.t() @ x64}[name[:2]]()
+                got = fn().double()
+                err = f'  rel L2 err vs fp64 {float((got - want).norm() / want.norm()):.2e}'
+            print(f'{name} M={M:5d} K={K:5d} N={N:5d}  {t:8.1f} us  {fl / t / 1e6:7.1f} TFLOP/s{err}', flush=True)
 
 
 if __name__ == '__main__':
