@@ -49,7 +49,7 @@ def parse_args(argv=None):
     p.add_argument('--save-every', type=int, default=10)
     p.add_argument('--visualize-every', type=int, default=5)
     # not in the reference: operand precision of the MFMA kernels (tensors and checkpoints stay fp32)
-    p.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16'])
+    p.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'bf16', 'fp32_split'])
     # not in the reference: replay the training step from a captured hipGraph (one process per node only)
     p.add_argument('--hip-graph', action='store_true')
     # not in the reference: render the Moving-MNIST frames on the GPU (same clips, no DataLoader workers)
