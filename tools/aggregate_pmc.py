@@ -41,7 +41,7 @@ def bench_label(name):
     m = re.match(r'void conv_wgrad_kernel<Tile<(\d+), (\d+), .*?>, (true|false)>', name)
     if m:
         return f'conv_wgrad_kernel<T{m.group(1)}x{m.group(2)}>'
-    m = re.match(r'void gemm_kernel<Tile<.*?>, (\d), (true|false)>', name)
+    m = re.match(r'void gemm_kernel<Tile<.*?>, (\d), (?:\d|true|false)>', name)
     if m:
         return f"gemm_kernel<{('nt', 'nn', 'tn')[int(m.group(1))]}>"
     m = re.match(r'void small_gemm_kernel<(\d), (true|false)>', name)
