@@ -31,6 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--precision', default='fp32')
+    ap.add_argument('--layers', type=int, default=0, help='only the first N layer shapes (0: all)')
     ap.add_argument('--error', action='store_true', help='also print the relative L2 error against an fp64 product')
     a = ap.parse_args()
     ops.set_precision(a.precision)
@@ -38,7 +39,7 @@ def main():
     # (rows of the activation, in features, out features) of the Linear layers that matter
     layers = [(4864, 8192, 512), (5120, 640, 4096), (4864, 512, 1024), (4864, 256, 1024), (5120, 256, 512),
               (256, 4096, 512)]
-    for M, K, N in layers:
+    for M, K, N in (layers[:a.layers] if a.layers else layers):
         x = torch.randn(M, K, device=dev)
         w = torch.randn(N, K, device=dev) * 0.05
         b = torch.randn(N, device=dev)
