@@ -2460,6 +2460,91 @@ __global__ void __launch_bounds__(256) deconv_final_kernel(DeconvFinalArgs g) {
   }
 }
 
+// The same kernel for a channel count known at compile time (Cin = 16 NCB): the tap weights take 4 NCB
+// registers instead of 64, and a wave keeps the loads of U pixel blocks in flight at once.
+template <int NCB, int U>
+__global__ void __launch_bounds__(256) deconv_final_fixed_kernel(DeconvFinalArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float contrib[];   // [(R+2)*W pixels][16 taps]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j16 = lane & 15, q = lane >> 4;
+  const int W = g.W, H = g.H, WO = 2 * W;
+  const int64_t n = blockIdx.x / g.bands;
+  const int a0 = (int)(blockIdx.x % g.bands) * g.R;
+  float wa[NCB][4];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) wa[cb][s2] = g.w[(cb * 16 + 4 * q + s2) * 16 + j16];
+  float4 sc[NCB], sh[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    sc[cb] = g.in_scale ? *reinterpret_cast<const float4*>(g.in_scale + cb * 16 + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+    sh[cb] = g.in_scale ? *reinterpret_cast<const float4*>(g.in_shift + cb * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int rows_in = g.R + 2;                   // halo row above and below
+  const int nblk = (rows_in * W + 15) / 16;
+  for (int blk0 = wave; blk0 < nblk; blk0 += 4 * U) {
+    float4 v[U][NCB];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = (blk0 + 4 * u) * 16 + j16;
+      const int ar = p >> g.lw, b = p & (W - 1);
+      const int a = a0 - 1 + ar;
+      ok[u] = ar < rows_in && a >= 0 && a < H;
+      const float* px = g.x + ((n * H + (ok[u] ? a : 0)) * W + b) * (NCB * 16) + 4 * q;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) v[u][cb] = *reinterpret_cast<const float4*>(px + cb * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = (blk0 + 4 * u) * 16 + j16;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        float4 t = v[u][cb];
+        if (g.in_scale) {
+          t.x = fmaf(t.x, sc[cb].x, sh[cb].x); t.y = fmaf(t.y, sc[cb].y, sh[cb].y);
+          t.z = fmaf(t.z, sc[cb].z, sh[cb].z); t.w = fmaf(t.w, sc[cb].w, sh[cb].w);
+        }
+        if (g.in_act == DVAE_ACT_LRELU) { t.x = lrelu(t.x); t.y = lrelu(t.y); t.z = lrelu(t.z); t.w = lrelu(t.w); }
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][0], t.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][1], t.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][2], t.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][3], t.w, acc, 0, 0, 0);
+      }
+      if ((p >> g.lw) < rows_in)
+        *reinterpret_cast<float4*>(contrib + (int64_t)p * 16 + 4 * q) =
+            ok[u] ? make_float4(acc[0], acc[1], acc[2], acc[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  // gather: output (ho, wo) = sum over the 2x2 input pixels that reach it, in a fixed order
+  const float bv = g.bias ? g.bias[0] : 0.f;
+  float* yo = g.y + (n * 2 * H + 2 * a0) * WO;
+  for (int i = threadIdx.x; i < 2 * g.R * WO; i += 256) {
+    const int orow = i / WO, wo = i - orow * WO;
+    const int ho = 2 * a0 + orow;
+    const int ah = (ho + 1) >> 1, khh = (ho & 1) ? 0 : 1;
+    const int bh = (wo + 1) >> 1, kwh = (wo & 1) ? 0 : 1;
+    float v = bv;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const int a = ah - dy, kh = khh + 2 * dy;
+      if (a < 0 || a >= H) continue;
+      const int ar = a - (a0 - 1);
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int b = bh - dx, kw = kwh + 2 * dx;
+        if (b < 0 || b >= W) continue;
+        v += contrib[(ar * W + b) * 16 + kh * 4 + kw];
+      }
+    }
+    if (g.out_act == DVAE_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+    yo[i] = v;
+  }
+}
+
 extern "C" int dvae_deconv4s2_final_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
                                             const float* w, const float* bias, int out_act, float* y, int64_t N,
                                             int64_t H, int64_t W, int64_t Cin, dvae_stream_t stream) {
@@ -2475,7 +2560,13 @@ extern "C" int dvae_deconv4s2_final_fwd_f32(const float* x, const float* in_scal
   g.R = H >= 16 ? 16 : (int)H;     // rows per band: the two halo rows are read twice, so not too few
   g.bands = (int)(H / g.R);
   const size_t lds = (size_t)(g.R + 2) * W * 16 * 4;
-  hipLaunchKernelGGL(deconv_final_kernel, dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);
+  const bool vec_affine = in_scale == nullptr || (aligned16(in_scale) && aligned16(in_shift));
+  if (Cin == 32 && vec_affine)
+    hipLaunchKernelGGL((deconv_final_fixed_kernel<2, 4>), dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);
+  else if (Cin == 64 && vec_affine)
+    hipLaunchKernelGGL((deconv_final_fixed_kernel<4, 2>), dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);
+  else
+    hipLaunchKernelGGL(deconv_final_kernel, dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);
   DVAE_LAUNCH_CHECK("deconv4s2_final_fwd");
   return 0;
 }
