@@ -417,23 +417,33 @@ __global__ void __launch_bounds__(256) conv_c1_kernel(ConvArgs g) {
   }
   const int64_t ngroups = (g.M + 15) / 16;
   const bool vec_store = (g.Cout & 3) == 0;
-  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
-    const int64_t m = grp * 16 + i16;
-    const bool mok = m < g.M;
-    const int b = (int)(m & ((1 << g.lw) - 1));
-    const int a = (int)((m >> g.lw) & ((1 << g.lh) - 1));
-    const int64_t n = m >> (g.lw + g.lh);
-    const float* img = g.x + n * g.H * g.W;
-    const int wi = 2 * b - 1 + kq;
-    const bool wok = mok && wi >= 0 && wi < g.W;
-    float xv[4];
+  // two pixel groups per pass: the gathers of both are issued before either is multiplied and stored
+  constexpr int U = 2;
+  for (int64_t grp0 = (int64_t)blockIdx.x * 4 + wave; grp0 < ngroups; grp0 += (int64_t)gridDim.x * 4 * U) {
+    float xvu[U][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int hi = 2 * a - 1 + r;
-      const bool ok = wok && hi >= 0 && hi < g.H;
-      const float v = *(ok ? img + hi * g.W + wi : g.x);
-      xv[r] = ok ? v : 0.f;
+    for (int u = 0; u < U; ++u) {
+      const int64_t m = (grp0 + (int64_t)u * gridDim.x * 4) * 16 + i16;
+      const bool mok = m < g.M;
+      const int b = (int)(m & ((1 << g.lw) - 1));
+      const int a = (int)((m >> g.lw) & ((1 << g.lh) - 1));
+      const int64_t n = mok ? m >> (g.lw + g.lh) : 0;
+      const float* img = g.x + n * g.H * g.W;
+      const int wi = 2 * b - 1 + kq;
+      const bool wok = mok && wi >= 0 && wi < g.W;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int hi = 2 * a - 1 + r;
+        const bool ok = wok && hi >= 0 && hi < g.H;
+        const float v = *(ok ? img + hi * g.W + wi : g.x);
+        xvu[u][r] = ok ? v : 0.f;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const int64_t m = (grp0 + (int64_t)u * gridDim.x * 4) * 16 + i16;
+    const bool mok = m < g.M;
+    const float (&xv)[4] = xvu[u];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -477,6 +487,7 @@ __global__ void __launch_bounds__(256) conv_c1_kernel(ConvArgs g) {
           s2[cb][r] += dz * ((yv[r] - bmu[cb][r]) * bis[cb][r]);
         }
       }
+    }
     }
   }
   if (g.stats) {
