@@ -728,8 +728,8 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
 }
 
 // The same row-ring scheme one size up (Cin*Cout <= 8192, e.g. 128 -> 64 on 8-pixel-wide frames): a
-// phase's filter no longer fits one wave, so a workgroup takes ONE sub-pixel phase (blockIdx.x & 3;
-// the four workgroups of a row run share their input rows through L2) and its four waves hold sixteen
+// phase's filter no longer fits one wave, so a workgroup takes ONE sub-pixel phase (the four
+// workgroups of a row run are placed on one XCD and share their input rows through its L2) and its four waves hold sixteen
 // output channels each ([16][4 taps][Cin] = 128 registers per lane at Cin = 128).  A group of sixteen
 // pixels is two rows of eight, so the row a lane reads depends on the lane: rows outside the frame are
 // redirected to a ninth, all-zero slot instead of being skipped.
@@ -741,8 +741,16 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows8_kernel(ConvArg
   constexpr int NLD = (W * C4 + 255) / 256;
   __shared__ __attribute__((aligned(16))) float ring[9 * SLOT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int phase = blockIdx.x & 3, ph = phase >> 1, pw = phase & 1;
-  const int bx = blockIdx.x >> 2, gx = gridDim.x >> 2;
+  // The four phases of a row run read the same input rows.  Workgroups go to the eight XCDs in turn
+  // (id mod 8), so with a multiple of eight runs the four are numbered eight apart: same XCD, same L2.
+  const int gx = gridDim.x >> 2;
+  int phase = blockIdx.x & 3, bx = blockIdx.x >> 2;
+  if ((gx & 7) == 0) {
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    phase = j & 3;
+    bx = (j >> 2) * 8 + x;
+  }
+  const int ph = phase >> 1, pw = phase & 1;
   const int i16 = lane & 15, kq = lane >> 4;
   const int H = g.H;
   // component m of wa[t][u] multiplies channel 16u + 4kq + m of tap t into output channel 16 wave + i16
@@ -1901,7 +1909,16 @@ __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
   __shared__ __attribute__((aligned(16))) float qbuf[2][2][QROW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, kq = lane >> 4;
-  const int dh = blockIdx.x & 3, z = blockIdx.x >> 2, nsplit = gridDim.x >> 2;
+  // The four filter rows of a split read the same P rows and overlapping Q rows.  Workgroups go to the
+  // eight XCDs in turn (id mod 8), so with a number of splits that is a multiple of eight the four are
+  // numbered eight apart: same XCD, same L2, dispatched together.
+  const int nsplit = gridDim.x >> 2;
+  int dh = blockIdx.x & 3, z = blockIdx.x >> 2;
+  if ((nsplit & 7) == 0) {
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    dh = j & 3;
+    z = (j >> 2) * 8 + x;
+  }
   const int Hs = g.Hs;
 
   const int lp4 = threadIdx.x % P4, lq4 = threadIdx.x % Q4;
