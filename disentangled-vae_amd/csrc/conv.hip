@@ -252,11 +252,18 @@ struct ConvALoader {
 template <class T, int MODE, bool C1, bool BF, bool BNS>
 __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * Core<T, BF>::STAGE];
-  // transposed conv: the four sub-pixel phases of one M tile sit in adjacent workgroups, so the input
-  // tile they share is fetched from HBM once and re-read through L2
-  const int phase = MODE == 1 ? (int)(blockIdx.x & 3) : 0, ph = phase >> 1, pw = phase & 1;
-  const int bx = MODE == 1 ? (int)(blockIdx.x >> 2) : (int)blockIdx.x;
+  // transposed conv: the four sub-pixel phases of one M tile share its input tile.  Workgroups go to
+  // the eight XCDs in turn (id mod 8), so with a multiple of eight tile columns the four are numbered
+  // eight apart (same XCD, same L2); otherwise they are adjacent and meet in the last-level cache.
   const int gx = MODE == 1 ? (int)(gridDim.x >> 2) : (int)gridDim.x;
+  int phase = MODE == 1 ? (int)(blockIdx.x & 3) : 0;
+  int bx = MODE == 1 ? (int)(blockIdx.x >> 2) : (int)blockIdx.x;
+  if (MODE == 1 && (gx & 7) == 0) {
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    phase = j & 3;
+    bx = (j >> 2) * 8 + x;
+  }
+  const int ph = phase >> 1, pw = phase & 1;
   const int64_t n0 = (int64_t)blockIdx.y * T::BN;
   const int ktiles = (g.K + 31) / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
