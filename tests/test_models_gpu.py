@@ -149,7 +149,9 @@ FULL['disentangled_128_wide'] = dict(content_dim=128, motion_dim=128, content_ch
                                      content_feature_dim=512, motion_feature_dim=512, lstm_hidden=256, lstm_layers=1,
                                      bidirectional=True, sequence_length=3)
 CASES = [('disentangled', 4, 20, 64), ('lstm', 4, 20, 64), ('baseline', 4, 20, 64),
-         ('disentangled_128_narrow', 2, 6, 128), ('disentangled_128_wide', 4, 3, 128)]
+         ('disentangled_128_narrow', 2, 6, 128), ('disentangled_128_wide', 4, 3, 128),
+         # ragged: odd batch with few frames, a single clip of two frames, single-frame clips
+         ('disentangled', 3, 5, 64), ('lstm', 1, 2, 64), ('baseline', 5, 1, 64)]
 
 
 @pytest.mark.parametrize('name,B,T,size', CASES)
