@@ -344,6 +344,9 @@ def main():
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                     help='operand precision of the MFMA kernels for the headline number')
     ap.add_argument('--no-extras', action='store_true', help='skip the inference and bf16-variant measurements')
+    ap.add_argument('--host-batches', default='', choices=['', 'serial', 'prefetch'],
+                    help='feed every step from pinned host memory over PCIe: copied on the step stream (serial) or one '
+                         'batch ahead on a side stream (prefetch); the headline value keeps batches resident in HBM')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group and use the data-parallel step even with one rank '
                          '(exercises the multi-GPU code path on a single GPU)')
@@ -450,6 +453,35 @@ def main():
     else:
         model.eval()
         step = infer_step
+    if args.host_batches:
+        # PCIe-inclusive variant: the same step fed from pinned host memory
+        host_ring = [v.cpu().pin_memory() for v in ring]
+        inner = step
+        if args.host_batches == 'serial':
+            dev_buf = torch.empty_like(ring[0])
+
+            def step(i):                                    # noqa: F811
+                dev_buf.copy_(host_ring[i % len(host_ring)], non_blocking=True)
+                ring[i % len(ring)] = dev_buf
+                return inner(i)
+        else:
+            copy_stream = torch.cuda.Stream()
+            bufs = [torch.empty_like(ring[0]) for _ in range(2)]
+            events = [None, None]
+
+            def upload(i):
+                copy_stream.wait_stream(torch.cuda.current_stream())      # the buffer's last reader is queued
+                with torch.cuda.stream(copy_stream):
+                    bufs[i % 2].copy_(host_ring[i % len(host_ring)], non_blocking=True)
+                    events[i % 2] = torch.cuda.Event()
+                    events[i % 2].record(copy_stream)
+            upload(0)
+
+            def step(i):                                    # noqa: F811
+                torch.cuda.current_stream().wait_event(events[i % 2])
+                ring[i % len(ring)] = bufs[i % 2]
+                upload(i + 1)       # waits for step i-1 (the other buffer's last reader), then runs beside step i
+                return inner(i)
     elapsed, last = measure(step, args.steps, args.warmup)
     value = world * B * args.steps / elapsed
     prec_label = 'fp32 MFMA' if args.precision == 'fp32' else 'bf16 MFMA operands, fp32 accumulate and storage'
@@ -461,7 +493,7 @@ def main():
         'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
         'config': {'workload': f"{cfg['name']} ({args.config}) {args.mode} step, beta=4, {T}x{size}x{size} clips, "
-                               f"batch {B}/GPU, {prec_label}, {('hipGraph replay' + (' (backward graph, one all-reduce, update graph)' if use_dp else '')) if use_graph else 'eager launches'}",
+                               f"batch {B}/GPU, {prec_label}, {('batches from pinned host memory (' + args.host_batches + '), ') if args.host_batches else ''}{('hipGraph replay' + (' (backward graph, one all-reduce, update graph)' if use_dp else '')) if use_graph else 'eager launches'}",
                    'global_batch': B * world, 'params': n_params,
                    'parallelism': f'dp{world}'},
     }

@@ -115,6 +115,7 @@ def main(argv=None):
         val_size=cfg.data.val_size, test_size=cfg.data.test_size, sequence_length=cfg.data.sequence_length,
         frame_size=cfg.data.frame_size, num_digits=cfg.data.num_digits, num_workers=cfg.data.num_workers,
         seed=cfg.data.seed, rank=rank, world_size=world,
+        pin_memory=not args.gpu_render,          # host batches are uploaded asynchronously, one batch ahead
         render_device=torch.device('cuda', torch.cuda.current_device()) if args.gpu_render else None)
     trainer = create_trainer(cfg, train_loader, val_loader)
     if args.hip_graph:

@@ -80,6 +80,47 @@ def _map_tensors(o, fn):
     return o
 
 
+class DevicePrefetcher:
+    """Iterates a loader of (video, metadata) host batches one batch ahead: batch i+1 is copied to the
+    device on a side stream (asynchronously when the loader pins its memory) while step i computes, so
+    the PCIe transfer is off the step's critical path.  Batches already on the device pass through."""
+
+    def __init__(self, loader, device: torch.device):
+        self.loader, self.device = loader, torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _upload(self, batch):
+        video, meta = batch
+        if video.is_cuda:
+            return video, meta, None
+        with torch.cuda.stream(self.stream):
+            dv = video.to(self.device, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return dv, meta, done
+
+    def __iter__(self):
+        pending = None
+        for batch in self.loader:
+            nxt = self._upload(batch)
+            if pending is not None:
+                yield self._hand_over(pending)
+            pending = nxt
+        if pending is not None:
+            yield self._hand_over(pending)
+
+    def _hand_over(self, item):
+        dv, meta, done = item
+        if done is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(done)
+            dv.record_stream(cur)           # allocated on the copy stream, consumed on the compute stream
+        return dv, meta
+
+
 class Trainer:
 
     def __init__(self, model: nn.Module, config: ExperimentConfig, train_loader, val_loader,
@@ -228,10 +269,10 @@ class Trainer:
         acc = None
         last = None
         n = 0
-        bar = tqdm(self.train_loader, desc=f'Epoch {self.current_epoch}', dynamic_ncols=True, leave=True,
-                   mininterval=0.5, disable=self.rank != 0) if self.rank == 0 else self.train_loader
+        batches = DevicePrefetcher(self.train_loader, self.device)
+        bar = tqdm(batches, desc=f'Epoch {self.current_epoch}', dynamic_ncols=True, leave=True,
+                   mininterval=0.5, disable=self.rank != 0) if self.rank == 0 else batches
         for video, _meta in bar:
-            video = video.to(self.device, non_blocking=True)
             last = self.train_step(video, beta)
             packed = last.packed.detach()
             acc = packed.clone() if acc is None else acc.add_(packed)
@@ -262,8 +303,7 @@ class Trainer:
         self.model.eval()
         beta = self.config.training.beta_vae          # the final beta, not the annealed one (reference :243)
         acc, last, n = None, None, 0
-        for video, _meta in self.val_loader:
-            video = video.to(self.device, non_blocking=True)
+        for video, _meta in DevicePrefetcher(self.val_loader, self.device):
             last, _ = self._compute_loss(video, beta)
             acc = last.packed.clone() if acc is None else acc.add_(last.packed)
             n += 1
