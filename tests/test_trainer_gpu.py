@@ -387,3 +387,18 @@ def test_async_checkpoint_is_a_consistent_snapshot(tmp_path):
     tr.save_checkpoint('c.pt')
     with pytest.raises(RuntimeError, match='checkpoint failed'):
         tr.wait_for_checkpoint()
+
+
+def test_device_prefetcher_hands_over_every_batch_in_order():
+    """One-batch-ahead upload on a side stream: same batches, same order, device batches untouched."""
+    from training.trainer import DevicePrefetcher
+    host = [(torch.full((2, 3, 1, 8, 8), float(i)).pin_memory(), {'i': i}) for i in range(5)]
+    got = list(DevicePrefetcher(host, torch.device('cuda')))
+    assert len(got) == 5
+    for i, (v, meta) in enumerate(got):
+        assert v.is_cuda and meta == {'i': i}
+        assert torch.equal(v.cpu(), host[i][0])
+    on_device = [(torch.ones(1, 2, 1, 8, 8, device='cuda'), None)]
+    out = list(DevicePrefetcher(on_device, torch.device('cuda')))
+    assert out[0][0] is on_device[0][0]
+    assert list(DevicePrefetcher([], torch.device('cuda'))) == []
