@@ -154,6 +154,17 @@ CASES = [('disentangled', 4, 20, 64), ('lstm', 4, 20, 64), ('baseline', 4, 20, 6
          ('disentangled', 3, 5, 64), ('lstm', 1, 2, 64), ('baseline', 5, 1, 64)]
 
 
+def test_full_size_step_in_fp32_split_mode_meets_the_fp32_bars():
+    """The opt-in mode that forms the Linear layers' fp32 products from bf16 MFMA products is held to the
+    same bars as the default fp32 path: whole training step of the DisentangledVAE against the fp64 oracle."""
+    from hipvae import ops
+    ops.set_precision('fp32_split')
+    try:
+        test_full_size_step_against_oracle('disentangled', 4, 20, 64)
+    finally:
+        ops.set_precision('fp32')
+
+
 @pytest.mark.parametrize('name,B,T,size', CASES)
 def test_full_size_step_against_oracle(name, B, T, size):
     """The three JSON configurations at their real layer sizes (B=4), and the 128x128 five-level
