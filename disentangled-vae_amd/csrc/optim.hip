@@ -81,17 +81,17 @@ mt_scale_kernel(MTTable t, const float* __restrict__ coef) {
   for (int64_t i = base + threadIdx.x; i < end; i += 256) g[i] *= c;
 }
 
-// `dyn` (optional, device): {step count, learning rate}.  When given, the bias corrections and the
-// step size are derived from it inside the kernel, so a captured graph replays correctly as the
-// step count and the learning rate move; the host-side scalars are ignored.
+// `dyn` (optional, device): {step count, learning rate, 1 - beta1^step, sqrt(1 - beta2^step)}, kept up
+// to date by adam_advance_kernel.  When given, the step size and the bias corrections are read from it,
+// so a captured graph replays correctly as the step count and the learning rate move; the host-side
+// scalars are ignored.
 __global__ void __launch_bounds__(256)
 mt_adam_kernel(MTTable t, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
                const float* __restrict__ grad_coef, const float* __restrict__ dyn) {
   if (dyn) {
-    const float step = dyn[0];
     lr = dyn[1];
-    bc1 = 1.f - powf(beta1, step);
-    bc2_sqrt = sqrtf(1.f - powf(beta2, step));
+    bc1 = dyn[2];
+    bc2_sqrt = dyn[3];
   }
   const int ti = mt_find(t, blockIdx.x);
   const int64_t base = (int64_t)(blockIdx.x - t.chunk_start[ti]) * MT_CHUNK;
@@ -190,13 +190,22 @@ extern "C" int dvae_scale_tensors_f32(int64_t n, float* const* tensors, const in
   return 0;
 }
 
-__global__ void adam_advance_kernel(float* dyn) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) dyn[0] += 1.f;
+// The corrections are formed in double from the double-precision betas and rounded to fp32 once, which is
+// what a host that computes 1 - beta^t in double and passes it as a float argument does: a replayed step
+// and an eagerly launched one see the same bits.
+__global__ void adam_advance_kernel(float* dyn, double beta1, double beta2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float step = dyn[0] + 1.f;
+    dyn[0] = step;
+    dyn[2] = (float)(1.0 - pow(beta1, (double)step));
+    dyn[3] = sqrtf((float)(1.0 - pow(beta2, (double)step)));
+  }
 }
 
-extern "C" int dvae_adam_advance_f32(float* dyn, dvae_stream_t stream) {
+extern "C" int dvae_adam_advance_f32(float* dyn, double beta1, double beta2, dvae_stream_t stream) {
   DVAE_REQUIRE(dyn != nullptr, "adam_advance: null state");
-  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, ST(stream), dyn);
+  DVAE_REQUIRE(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0, "adam_advance: betas must be in [0, 1)");
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, ST(stream), dyn, beta1, beta2);
   DVAE_LAUNCH_CHECK("adam_advance");
   return 0;
 }

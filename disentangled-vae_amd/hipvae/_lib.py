@@ -4,7 +4,7 @@ There is no fallback: if the library has not been built, importing this module r
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 # torch must be imported first: it brings its own HIP runtime (libamdhip64), and the kernels have to
 # run on that same runtime instance to share torch's device context, streams and allocations.
@@ -89,7 +89,7 @@ SIGNATURES = {
     'dvae_scale_tensors_f32': (I, [L, POINTER(c_void_p), POINTER(c_int64), P, P]),
     'dvae_adam_step_f32': (I, [L, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                POINTER(c_int64), F, F, F, F, F, F, F, P, P, P]),
-    'dvae_adam_advance_f32': (I, [P, P]),
+    'dvae_adam_advance_f32': (I, [P, c_double, c_double, P]),
 }
 
 MISSING = []

@@ -638,7 +638,8 @@ def scale_tensors(tensors: List[Tensor], coef: Tensor, table: Optional[TensorTab
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
               grad_coef: Optional[Tensor], table: Optional[TensorTable] = None, dyn: Optional[Tensor] = None):
-    """dyn: device tensor {step count, learning rate}; when given it overrides lr/bc1/bc2."""
+    """dyn: device tensor {step count, learning rate, 1-beta1^t, sqrt(1-beta2^t)} maintained by
+    adam_advance; when given it overrides lr/bc1/bc2."""
     table = table or TensorTable()
     n, (p, g, m, v), numel = table.get([params, grads, exp_avg, exp_avg_sq])
     check(lib.dvae_adam_step_f32(n, p, g, m, v, numel, float(lr), float(beta1), float(beta2), float(eps),
@@ -646,5 +647,8 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_
           'adam_step')
 
 
-def adam_advance(dyn: Tensor):
-    check(lib.dvae_adam_advance_f32(_p(dyn), _stream()), 'adam_advance')
+def adam_advance(dyn: Tensor, beta1: float, beta2: float):
+    """dyn[0] += 1 and the two bias corrections for the new step count, on the stream."""
+    if not (dyn.is_cuda and dyn.dtype == torch.float32 and dyn.numel() >= 4 and dyn.is_contiguous()):
+        raise RuntimeError("adam_advance: dyn must be four contiguous fp32 values on the GPU")
+    check(lib.dvae_adam_advance_f32(_p(dyn), float(beta1), float(beta2), _stream()), 'adam_advance')

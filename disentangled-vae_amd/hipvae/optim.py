@@ -20,24 +20,33 @@ class FusedAdam(torch.optim.Adam):
         self._tables = {}
         self._norm_out = None          # [norm, clip coefficient] on the device
         self._pending_coef = None
-        self._dyn = None               # device {step count, learning rate} for graph replay
+        self._dyn = None               # device {step count, learning rate, bias corrections} for graph replay
         self._dyn_lr = None
         self._replayed = 0             # steps taken by graph replays, not yet written to state['step']
 
     # ---- device-resident step state (needed when step() is captured into a hipGraph) -----------
     def enable_device_state(self):
         """Keep the step count and learning rate in device memory and let the Adam kernel derive its
-        bias corrections from them, so that a captured graph stays correct as they change."""
+        bias corrections from them, so that a captured graph stays correct as they change.  The device
+        pair is allocated once per optimiser and only refreshed in place afterwards: every graph
+        captured from this optimiser holds its raw address."""
         if len(self.param_groups) != 1:
             raise RuntimeError("device-resident step state supports a single parameter group")
         p0 = self.param_groups[0]['params'][0]
+        self._flush_replayed()
         steps = 0.0
         for p in self.param_groups[0]['params']:
             if p in self.state and len(self.state[p]):
                 steps = float(self.state[p]['step'])
                 break
-        self._dyn = torch.tensor([steps, float(self.param_groups[0]['lr'])], dtype=torch.float32, device=p0.device)
-        self._dyn_lr = float(self.param_groups[0]['lr'])
+        lr = float(self.param_groups[0]['lr'])
+        # slots 2 and 3 (the bias corrections) are rewritten by every adam_advance before they are read
+        host = torch.tensor([steps, lr, 1.0, 1.0], dtype=torch.float32)
+        if self._dyn is None:
+            self._dyn = host.to(p0.device)
+        else:
+            self._dyn.copy_(host)
+        self._dyn_lr = lr
         return self._dyn
 
     def sync_device_lr(self):
@@ -63,8 +72,26 @@ class FusedAdam(torch.optim.Adam):
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
+        """torch.optim.Adam.load_state_dict, except that moment tensors which already exist keep their
+        storage (the loaded values are copied into them): captured graphs hold their addresses."""
         self._replayed = 0
+        old = {p: dict(st) for p, st in self.state.items()}
         super().load_state_dict(state_dict)
+        for p, st in self.state.items():
+            # the step count is read on the host at every step: keep it there (a checkpoint loaded with
+            # map_location=<gpu> would otherwise turn that read into a device synchronisation, which a
+            # stream under graph capture refuses)
+            if torch.is_tensor(st.get('step')) and st['step'].is_cuda:
+                st['step'] = st['step'].cpu()
+            prev = old.get(p)
+            if not prev:
+                continue
+            for k in ('exp_avg', 'exp_avg_sq'):
+                a, b = prev.get(k), st.get(k)
+                if a is not None and b is not None and a is not b and a.shape == b.shape and a.device == b.device:
+                    a.copy_(b)
+                    st[k] = a
+        self._tables = {}
         if self._dyn is not None:
             self.enable_device_state()
 
@@ -104,7 +131,7 @@ class FusedAdam(torch.optim.Adam):
         coef, self._pending_coef = self._pending_coef, None
         self._flush_replayed()
         if self._dyn is not None:
-            ops.adam_advance(self._dyn)
+            ops.adam_advance(self._dyn, *self.param_groups[0]['betas'])
         for gi, group in enumerate(self.param_groups):
             params, grads, m, v = [], [], [], []
             step_val = None

@@ -237,8 +237,11 @@ class Trainer:
         from hipvae.graph import GraphedDataParallelStep, GraphedTrainStep
         key = (tuple(video.shape), float(beta))
         g = self._graphs.get(key)
-        if g is None:
-            while len(self._graphs) >= 2:
+        if g is not None:
+            self._graphs[key] = self._graphs.pop(key)          # most recently used last
+        else:
+            # room for the full and the ragged last batch of the current and the previous beta
+            while len(self._graphs) >= 4:
                 self._graphs.pop(next(iter(self._graphs)))
             loss_of = lambda m, v: self._compute_loss(v, beta)[0]
             clip = self.config.training.gradient_clip
@@ -266,6 +269,11 @@ class Trainer:
         self.model.train()
         beta = self._get_beta(self.current_epoch)
         t = self.config.training
+        # a distributed sampler derives its shuffle from (seed, epoch): without this call every epoch
+        # would walk the clips in the same order
+        sampler = getattr(self.train_loader, 'sampler', None)
+        if hasattr(sampler, 'set_epoch'):
+            sampler.set_epoch(self.current_epoch)
         acc = None
         last = None
         n = 0
@@ -277,8 +285,11 @@ class Trainer:
             packed = last.packed.detach()
             acc = packed.clone() if acc is None else acc.add_(packed)
             n += 1
+            if self.global_step % t.log_every == 0 and (self.rank == 0 or self.distributed):
+                # the only per-step synchronisation; with several ranks the logged values are the mean
+                # over ranks (every rank takes part in the collective, rank 0 writes)
+                cur = self._unpack(last, self._rank_mean(packed.clone()).cpu())
             if self.rank == 0 and self.global_step % t.log_every == 0:
-                cur = self._unpack(last, packed.cpu())                 # the only per-step synchronisation
                 for k, v in cur.items():
                     self.writer.add_scalar(f'train/{k}', v, self.global_step)
                 self.writer.add_scalar('train/beta', beta, self.global_step)
@@ -294,9 +305,17 @@ class Trainer:
             self.global_step += 1
         if n == 0:
             return {}
-        out = self._unpack(last, (acc / n).cpu())
+        out = self._unpack(last, self._rank_mean(acc / n).cpu())
         out['beta'] = beta
         return out
+
+    def _rank_mean(self, packed: torch.Tensor) -> torch.Tensor:
+        """Mean of a packed loss vector over the ranks (for logging and the history only; the identity on
+        one rank).  Every rank must call it at the same points."""
+        if not self.distributed:
+            return packed
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        return packed / dist.get_world_size()
 
     @torch.no_grad()
     def validate(self) -> Dict[str, float]:
@@ -309,7 +328,7 @@ class Trainer:
             n += 1
         if n == 0:
             return {}
-        out = self._unpack(last, (acc / n).cpu())
+        out = self._unpack(last, self._rank_mean(acc / n).cpu())
         out['beta'] = beta
         return out
 
@@ -402,6 +421,10 @@ class Trainer:
         ckpt = torch.load(path, map_location=self.device, weights_only=False)
         self.model.load_state_dict(ckpt['model_state_dict'])
         self.optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+        # graphs captured before the load are dropped: they are re-captured against the loaded state on
+        # the next step (parameters and Adam moments keep their storage, but a capture also bakes in
+        # anything the optimiser created lazily at its first step)
+        self._graphs.clear()
         self.current_epoch = ckpt['epoch']            # resumes AT the saved epoch, as the reference does
         self.global_step = ckpt['global_step']
         self.best_val_loss = ckpt['best_val_loss']

@@ -328,14 +328,17 @@ int dvae_scale_tensors_f32(int64_t n, float* const* tensors, const int64_t* nume
                            dvae_stream_t stream);
 /* One Adam step on n tensors; gradients are multiplied by *grad_coef (device scalar, NULL = 1) as
  * they are read.  bias_correction1 = 1-beta1^t, bias_correction2 = 1-beta2^t computed by the caller,
- * unless dyn (device, {step count t, learning rate}) is given: then lr and both corrections are
- * derived from dyn inside the kernel, which is what lets a captured hipGraph replay the step while t
- * and the learning rate change.  dvae_adam_advance_f32 does dyn[0] += 1 on the stream. */
+ * unless dyn is given: four device floats {step count t, learning rate, 1-beta1^t, sqrt(1-beta2^t)};
+ * then lr and both corrections are read from dyn inside the kernel, which is what lets a captured
+ * hipGraph replay the step while t and the learning rate change.  dvae_adam_advance_f32 does
+ * dyn[0] += 1 on the stream and refreshes dyn[2], dyn[3] for the new count (computed in double from the
+ * double betas, rounded to fp32 once, like a host-side caller's float arguments); the caller owns
+ * dyn[1]. */
 int dvae_adam_step_f32(int64_t n, float* const* params, const float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2,
                        float eps, float weight_decay, float bias_correction1, float bias_correction2,
                        const float* grad_coef, const float* dyn, dvae_stream_t stream);
-int dvae_adam_advance_f32(float* dyn, dvae_stream_t stream);
+int dvae_adam_advance_f32(float* dyn, double beta1, double beta2, dvae_stream_t stream);
 
 #ifdef __cplusplus
 }

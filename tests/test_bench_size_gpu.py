@@ -1,0 +1,287 @@
+"""Parity at the sizes the benchmark times (DisentangledVAE, 256 clips x 20 frames = 5120 frames per step).
+
+The launchers pick different paths once a layer has hundreds of tiles: a second launch with narrower
+tiles for a partly filled last round of workgroups (convolutions without fused statistics, the NT
+GEMM), several M tiles per workgroup when a layer has more than 1024 of them, split-K by cost model.
+None of these is reached by the small cases of test_kernels_gpu.py, so each is checked here against an
+fp64 CPU computation of the same layer, followed by whole training steps of the model at the benchmark
+batch (fp32 and bf16-MFMA) against the fp64 oracle.
+
+Tolerances: fp32 kernels vs fp64, relative L2 <= 5e-6 (K up to 8192 accumulated in fp32); model-level
+bars as in test_models_gpu.py (outputs and losses 1e-4 relative, per-tensor gradients
+max(1e-4, 2 x the fp32 CPU restatement's own error against fp64)).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+from oracle import vae_oracle as O
+
+FRAMES = 5120          # 256 clips x 20 frames
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from hipvae import ops as _ops
+    assert torch.cuda.is_available()
+    assert _ops.get_precision() == 'fp32'
+    return _ops
+
+
+def dev(t):
+    return t.to('cuda', torch.float32).contiguous()
+
+
+def rel_err(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((got - ref).norm() / max(float(ref.norm()), 1e-30))
+
+
+def rnd32(*shape, seed=0, scale=1.0):
+    """fp32-representable normal draws (the fp64 reference then sees exactly the kernel's operands)"""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float32) * scale
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def conv_ref(x, w, transposed, chunk=512):
+    """fp64 convolution in chunks of frames (bounded host memory)"""
+    fn = F.conv_transpose2d if transposed else F.conv2d
+    w64 = w.double()
+    return torch.cat([fn(x[i:i + chunk].double(), w64, None, stride=2, padding=1) for i in range(0, x.shape[0], chunk)])
+
+
+# N, H_in, Cin, Cout, statistics, what the launcher does with it at this size
+CONV_BENCH = [
+    (FRAMES, 32, 32, 64, True),     # second encoder conv of the per-frame models: row-ring kernel, 5120 frames
+    (FRAMES, 16, 64, 128, True),    # 2560 row tiles with statistics: several M tiles per workgroup (> 1024 tiles)
+    (FRAMES, 16, 64, 128, False),   # the same layer as a data gradient: 2560 tiles = 5 full rounds
+    (FRAMES, 8, 128, 256, False),   # 1280 tiles of 128x128 = 2.5 rounds: 128-wide launch + 64-wide launch
+    (FRAMES, 8, 128, 256, True),    # with statistics: one launch
+    (4864, 32, 16, 32, True),       # motion encoder's second conv at 256 x 19 frames
+]
+
+
+@pytest.mark.parametrize('N,H,Cin,Cout,stats', CONV_BENCH)
+def test_conv_at_bench_size(ops, N, H, Cin, Cout, stats):
+    x = rnd32(N, Cin, H, H, seed=20)
+    w = rnd32(Cout, Cin, 4, 4, seed=21, scale=0.2)
+    ref = conv_ref(x, w, False)
+    y, st, nparts = ops.conv4s2_fwd(dev(nhwc(x)), None, None, ops.ACT_NONE, ops.pack_conv_w(dev(w)), stats)
+    assert rel_err(nchw(y), ref) < 5e-6
+    if stats:
+        s = st.double().sum(0).cpu()
+        assert rel_err(s[0], ref.sum(dim=(0, 2, 3))) < 1e-5
+        assert rel_err(s[1], (ref ** 2).sum(dim=(0, 2, 3))) < 1e-5
+
+
+DECONV_BENCH = [
+    (FRAMES, 4, 256, 128, True),    # first decoder block: 4 phases x 640 row tiles
+    (FRAMES, 4, 256, 128, False),   # the same as the data gradient of the 128 -> 256 conv
+    (FRAMES, 8, 128, 64, True),     # one phase per workgroup (8-wide frames)
+    (FRAMES, 16, 64, 32, True),     # row-ring kernel
+]
+
+
+@pytest.mark.parametrize('N,H,Cin,Cout,stats', DECONV_BENCH)
+def test_deconv_at_bench_size(ops, N, H, Cin, Cout, stats):
+    x = rnd32(N, Cin, H, H, seed=24)
+    w = rnd32(Cin, Cout, 4, 4, seed=25, scale=0.2)
+    sc, sh = 1 + 0.3 * rnd32(Cin, seed=26), 0.2 * rnd32(Cin, seed=27)
+    xin = O.leaky_relu(x.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    ref = conv_ref(xin, w, True)
+    y, st, _ = ops.deconv4s2_fwd(dev(nhwc(x)), dev(sc), dev(sh), ops.ACT_LRELU, ops.pack_deconv_w(dev(w)), stats)
+    assert rel_err(nchw(y), ref) < 5e-6
+    if stats:
+        s = st.double().sum(0).cpu()
+        assert rel_err(s[0], ref.sum(dim=(0, 2, 3))) < 1e-5
+        assert rel_err(s[1], (ref ** 2).sum(dim=(0, 2, 3))) < 1e-5
+
+
+WGRAD_BENCH = [(FRAMES, 4, 256, 128), (FRAMES, 8, 128, 64), (FRAMES, 16, 64, 32), (256, 4, 256, 128),
+               (256, 8, 128, 64)]
+
+
+@pytest.mark.parametrize('N,Hs,C1,C2', WGRAD_BENCH)
+def test_wgrad_at_bench_size(ops, N, Hs, C1, C2):
+    x = rnd32(N, C2, 2 * Hs, 2 * Hs, seed=31)
+    dy = rnd32(N, C1, Hs, Hs, seed=32, scale=0.1)
+    dw = torch.zeros(C1, C2, 4, 4, dtype=torch.float64)
+    for i in range(0, N, 512):
+        w = torch.zeros(C1, C2, 4, 4, dtype=torch.float64, requires_grad=True)
+        yy = F.conv2d(x[i:i + 512].double(), w, None, stride=2, padding=1)
+        dw += torch.autograd.grad(yy, w, dy[i:i + 512].double())[0]
+    got = ops.conv4s2_wgrad(dev(nhwc(dy)), None, None, ops.ACT_NONE, dev(nhwc(x)), None, None, ops.ACT_NONE)
+    assert rel_err(got, dw) < 1e-5
+
+
+# M, N, K: decoder fc (two-launch NT: 1280 tiles), motion-encoder fc, and shapes the advisor named
+GEMM_BENCH = [(5120, 4096, 640), (4864, 512, 8192), (2560, 4096, 64), (5120, 512, 256), (256, 512, 4096)]
+
+
+@pytest.mark.parametrize('M,N,K', GEMM_BENCH)
+def test_gemm_at_bench_size(ops, M, N, K):
+    a, b, bias = rnd32(M, K, seed=10), rnd32(N, K, seed=11), rnd32(N, seed=12)
+    ref = O.leaky_relu(a.double() @ b.double().t() + bias.double())
+    assert rel_err(ops.gemm_nt(dev(a), dev(b), dev(bias), ops.ACT_LRELU), ref) < 5e-6
+    # data gradient (NN) and weight gradient (TN) of the same layer
+    d = rnd32(M, N, seed=13)
+    assert rel_err(ops.gemm_nn(dev(d), dev(b)), d.double() @ b.double()) < 5e-6
+    assert rel_err(ops.gemm_tn(dev(d), dev(a)), d.double().t() @ a.double()) < 5e-6
+    base = rnd32(N, K, seed=15)
+    out = dev(base)
+    ops.gemm_tn(dev(d), dev(a), out=out, accumulate=True)
+    assert rel_err(out, base.double() + d.double().t() @ a.double()) < 5e-6
+
+
+class _KinkAt(torch.autograd.Function):
+    """LeakyReLU(0.2) with the exact forward value and a derivative that switches at x = thr instead of 0."""
+
+    @staticmethod
+    def forward(ctx, x, rel_thr):
+        thr = rel_thr * x.detach().pow(2).mean().sqrt()
+        ctx.save_for_backward(x > thr)
+        return torch.where(x > 0, x, x * O.LRELU_SLOPE)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return torch.where(mask, g, g * O.LRELU_SLOPE), None
+
+
+def _oracle_step(kind, sd, video, eps, tcfg, beta, layers, dtype, kink=None):
+    """kink: relative threshold (in units of each layer's rms pre-activation) at which LeakyReLU's
+    derivative switches; None = at zero, as defined."""
+    if kink is not None:
+        orig = O.leaky_relu
+        O.leaky_relu = lambda x: _KinkAt.apply(x, kink)
+        try:
+            return _oracle_step(kind, sd, video, eps, tcfg, beta, layers, dtype)
+        finally:
+            O.leaky_relu = orig
+    sdx = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+    keys = O.trainable_keys(sdx)
+    leaves = {k: sdx[k].clone().requires_grad_(True) for k in keys}
+    work = dict(sdx)
+    work.update(leaves)
+    ns = {}
+    out = O.model_forward(kind, work, video.to(dtype), [e.to(dtype) for e in eps], True, lstm_layers=layers,
+                          new_stats=ns)
+    loss = O.model_loss(kind, out, video.to(dtype), beta, tcfg)
+    grads = torch.autograd.grad(loss['total_loss'], [leaves[k] for k in keys])
+    out = {k: v.detach() for k, v in (out.items() if isinstance(out, dict) else
+                                      zip(('recon', 'z', 'mu', 'logvar'), out))}
+    return keys, out, {k: float(v.detach()) for k, v in loss.items() if torch.is_tensor(v) and v.numel() == 1}, grads, ns
+
+
+@pytest.mark.parametrize('kind,B', [('disentangled', 256), ('lstm', 64), ('baseline', 256)])
+def test_training_step_at_bench_batch_against_oracle(kind, B):
+    """One whole training step at the benchmark's batch and real layer widths (T=20, 64x64): every launch
+    the benchmark times is on this path.  HIP outputs, losses, gradients and BatchNorm buffers vs the fp64
+    oracle, with the fp32 CPU restatement's own distance from fp64 as the yard-stick for gradients.
+
+    The gradient is discontinuous where a LeakyReLU input is zero.  With 10^5..10^8 activations per layer
+    some lie within fp32 rounding distance of zero, and an fp32 evaluation (this one, or the reference's)
+    may take the other branch for them than the fp64 oracle does; in a small layer (the content encoder
+    sees 256 frames) a single such element moves a whole tensor's gradient by 1e-3.  The oracle therefore
+    also measures, per tensor, how far its fp64 gradient moves when every activation within 1e-5 of the
+    kink (relative to its layer's rms) changes branch; that distance joins the bar:
+    max(1e-4, 2 x own fp32 error, kink sensitivity)."""
+    import models
+    from hipvae import rng
+    from test_models_gpu import FULL, SETTINGS, as_dict, loss_of, rel
+    T, size = 20, 64
+    torch.manual_seed(0)
+    m = models.get_model(kind, in_channels=1, **FULL[kind])
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    gen = torch.Generator().manual_seed(1)
+    video = (torch.rand(B, T, 1, size, size, generator=gen) > 0.9).float() * torch.rand(B, T, 1, size, size,
+                                                                                         generator=gen)
+    dim = FULL[kind].get('content_dim', FULL[kind].get('latent_dim'))
+    eps = [torch.randn(B, dim, generator=torch.Generator().manual_seed(100 + k)) for k in range(2)]
+    tcfg = dict(SETTINGS['tcfg'][kind])
+    if kind == 'disentangled':
+        tcfg.update(beta_content=4.0, beta_motion=4.0)           # the benchmark's beta
+    layers = FULL[kind].get('lstm_layers', 1)
+    keys, oout, oloss, ograds, ns = _oracle_step(kind, sd, video, eps, tcfg, 4.0, layers, torch.float64)
+    _, _, _, ograds32, _ = _oracle_step(kind, sd, video, eps, tcfg, 4.0, layers, torch.float32)
+    _, _, _, g_lo, _ = _oracle_step(kind, sd, video, eps, tcfg, 4.0, layers, torch.float64, kink=-1e-5)
+    _, _, _, g_hi, _ = _oracle_step(kind, sd, video, eps, tcfg, 4.0, layers, torch.float64, kink=1e-5)
+    m = m.cuda().train()
+    with rng.inject_eps(eps):
+        out = m(video.cuda())
+    losses = loss_of(kind, out, video.cuda(), tcfg, 4.0)
+    losses['total_loss'].backward()
+    for k, v in as_dict(kind, out).items():
+        r = rel(v.detach().cpu().numpy(), oout[k].numpy())
+        assert r < 1e-4, (k, r)
+    for k in ('total_loss', 'recon_loss', 'kl_loss'):
+        assert abs(losses[k].item() - oloss[k]) <= 1e-4 * abs(oloss[k]) + 1e-6, (k, losses[k].item(), oloss[k])
+    named = dict(m.named_parameters())
+    report = []
+    for k, og, og32, lo, hi in zip(keys, ograds, ograds32, g_lo, g_hi):
+        r = rel(named[k].grad.cpu().numpy(), og.numpy())
+        own = rel(og32.numpy(), og.numpy())
+        kink = rel(hi.numpy(), lo.numpy())
+        report.append((r / max(1e-4, 2 * own, kink), k, r, own, kink))
+    report.sort(reverse=True)
+    print(f'{kind} B={B}: worst gradient tensors (err, fp32 restatement own err, kink sensitivity):',
+          [(k, f'{r:.2e}', f'{own:.2e}', f'{kk:.2e}') for _, k, r, own, kk in report[:6]])
+    assert report[0][0] <= 1.0, report[0]
+    for k, v in ns.items():
+        got = m.state_dict()[k].cpu()
+        if v.is_floating_point():
+            assert rel(got.numpy(), v.numpy()) < 1e-4, k
+        else:
+            assert int(got) == int(v), k
+
+
+def test_bf16_training_step_at_bench_batch():
+    """BASELINE configuration 4's arithmetic (bf16 MFMA operands, fp32 accumulation) on the full-width
+    DisentangledVAE at 256 clips: stated tolerance against the fp64 oracle -- loss 2e-3 relative,
+    reconstructions and latent means 2e-2 relative L2, per-tensor gradients 2e-1 relative L2 (operands of
+    every product are rounded to 8 significand bits, forward and backward)."""
+    import models
+    from hipvae import ops as _ops, rng
+    from test_models_gpu import FULL, SETTINGS, loss_of, rel
+    kind, B, T, size = 'disentangled', 256, 20, 64
+    torch.manual_seed(0)
+    m = models.get_model(kind, in_channels=1, **FULL[kind])
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    gen = torch.Generator().manual_seed(1)
+    video = (torch.rand(B, T, 1, size, size, generator=gen) > 0.9).float() * torch.rand(B, T, 1, size, size,
+                                                                                         generator=gen)
+    eps = [torch.randn(B, 128, generator=torch.Generator().manual_seed(100 + k)) for k in range(2)]
+    tcfg = dict(SETTINGS['tcfg'][kind], beta_content=4.0, beta_motion=4.0)
+    keys, oout, oloss, ograds, _ = _oracle_step(kind, sd, video, eps, tcfg, 4.0, 1, torch.float64)
+    _ops.set_precision('bf16')
+    try:
+        m = m.cuda().train()
+        with rng.inject_eps(eps):
+            out = m(video.cuda())
+        losses = loss_of(kind, out, video.cuda(), tcfg, 4.0)
+        losses['total_loss'].backward()
+        torch.cuda.synchronize()
+    finally:
+        _ops.set_precision('fp32')
+    assert abs(losses['total_loss'].item() - oloss['total_loss']) <= 2e-3 * abs(oloss['total_loss'])
+    for k in ('recon', 'mu_content', 'mu_motion', 'logvar_content', 'logvar_motion'):
+        r = rel(out[k].detach().cpu().numpy(), oout[k].numpy())
+        assert r < 2e-2, (k, r)
+    named = dict(m.named_parameters())
+    errs = {k: rel(named[k].grad.cpu().numpy(), og.numpy()) for k, og in zip(keys, ograds)}
+    worst = max(errs, key=errs.get)
+    print(f'bf16 B={B}: gradient rel-L2 error median {np.median(list(errs.values())):.3e}, '
+          f'worst {errs[worst]:.3e} ({worst})')
+    assert errs[worst] < 2e-1, (worst, errs[worst])

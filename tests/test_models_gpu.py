@@ -216,9 +216,9 @@ def test_full_size_step_against_oracle(name, B, T, size):
     for k, og, og32 in zip(keys, ograds, ograds32):
         r = rel(named[k].grad.cpu().numpy(), og.numpy())
         own = rel(og32.numpy(), og.numpy())
-        # fp32 accumulation over K up to 8192 and B*T*H*W up to 327,680 rows; with a handful of frames
-        # per BatchNorm batch the fp32 CPU restatement itself strays further, and sets the bar then
-        assert r < max(5e-4, 2 * own), (k, r, own)
+        # the contract's bar: 1e-4, or twice what fp32 arithmetic itself (the CPU restatement in fp32)
+        # strays from fp64 on this tensor -- with a handful of frames per BatchNorm batch that is more
+        assert r < max(1e-4, 2 * own), (k, r, own)
     for k, v in ns.items():
         got = m.state_dict()[k].cpu()
         if v.is_floating_point():
