@@ -5,6 +5,7 @@
 #include "../../include/dvae_hip.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -278,6 +279,63 @@ extern "C" int dvae_recon_metrics_f32(const float* recon, const float* target, f
   hipLaunchKernelGGL(recon_metrics_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, nb, out,
                      (double)B, (double)T, (double)P, (double)max_val);
   DVAE_LAUNCH_CHECK("recon_metrics_finalize");
+  return 0;
+}
+
+// ---- the same metrics for callers that cannot allocate -------------------------------------------
+// The per-workgroup partial sums live in a file-scope device array instead of a caller-provided
+// workspace.  Every GPU holds its own copy of the array at its own address: the address is looked up
+// once per device (hipGetSymbolAddress with that device current) and only that pointer is ever handed
+// to a kernel -- the array's name in host code is a host-side stand-in, not a device address.
+#define NOALLOC_MAX_DEVICES 64
+static __device__ __align__(256) double scratch[2 * RL_MAX_BLOCKS];          // 32 KiB per GPU
+static double* g_scratch_ptr[NOALLOC_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+// device pointer of `scratch` on the current device (nullptr + error message on failure)
+static double* scratch_on_current_device() {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= NOALLOC_MAX_DEVICES) {
+    dvae_set_error("recon_metrics_noalloc: cannot identify the current device (%s, device %d, at most %d supported)",
+                   hipGetErrorString(e), dev, NOALLOC_MAX_DEVICES);
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr) {
+      dvae_set_error("recon_metrics_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+      return nullptr;
+    }
+    g_scratch_ptr[dev] = (double*)p;
+  }
+  return g_scratch_ptr[dev];
+}
+
+extern "C" int64_t dvae_recon_metrics_noalloc_max_elements(void) { return DVAE_NOALLOC_MAX_ELEMENTS; }
+
+extern "C" int dvae_recon_metrics_noalloc_f32(const float* recon, const float* target, float* out, int64_t B,
+                                              int64_t T, int64_t P, float max_val, dvae_stream_t stream) {
+  DVAE_REQUIRE(B > 0 && T >= 1 && P > 0 && P % 4 == 0, "recon_metrics_noalloc: need P%%4==0 (P=%ld)", (long)P);
+  DVAE_REQUIRE(B <= DVAE_NOALLOC_MAX_ELEMENTS / T / P,
+               "recon_metrics_noalloc: B*T*P = %ld*%ld*%ld elements per clip tensor exceeds the limit of %ld; use "
+               "dvae_recon_metrics_f32 with a caller-provided workspace",
+               (long)B, (long)T, (long)P, (long)DVAE_NOALLOC_MAX_ELEMENTS);
+  DVAE_REQUIRE(recon && target && out, "recon_metrics_noalloc: null argument");
+  DVAE_REQUIRE(((((uintptr_t)recon) | ((uintptr_t)target)) & 15) == 0,
+               "recon_metrics_noalloc: clips must be 16-byte aligned");
+  double* ws = scratch_on_current_device();
+  if (ws == nullptr) return -EIO;
+  // every partial the finalize kernel reads is written by this launch first: nothing to clear
+  const int nb = recon_blocks(B, P);
+  hipLaunchKernelGGL(recon_metrics_kernel, dim3(nb), dim3(256), 0, ST(stream), (const float4*)recon,
+                     (const float4*)target, ws, B * (P / 4), (int)T, P / 4);
+  DVAE_LAUNCH_CHECK("recon_metrics_noalloc");
+  hipLaunchKernelGGL(recon_metrics_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, nb, out,
+                     (double)B, (double)T, (double)P, (double)max_val);
+  DVAE_LAUNCH_CHECK("recon_metrics_noalloc_finalize");
   return 0;
 }
 

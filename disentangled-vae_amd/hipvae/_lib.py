@@ -34,6 +34,8 @@ SIGNATURES = {
     'dvae_recon_loss_ws_floats': (L, [L, L, L]),
     'dvae_recon_loss_fwd_f32': (I, [P, P, P, P, L, L, L, I, I, P]),
     'dvae_recon_metrics_f32': (I, [P, P, P, P, L, L, L, F, P]),
+    'dvae_recon_metrics_noalloc_max_elements': (L, []),
+    'dvae_recon_metrics_noalloc_f32': (I, [P, P, P, L, L, L, F, P]),
     'dvae_recon_loss_bwd_f32': (I, [P, P, P, P, L, L, L, I, F, P]),
     'dvae_reparam_fwd_f32': (I, [P, P, P, P, L, P]),
     'dvae_reparam_bwd_f32': (I, [P, P, P, P, P, L, P]),

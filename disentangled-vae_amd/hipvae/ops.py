@@ -102,6 +102,21 @@ def recon_metrics(recon: Tensor, target: Tensor, max_val: float = 1.0, out: Opti
     return out
 
 
+def recon_metrics_noalloc(recon: Tensor, target: Tensor, out: Tensor, max_val: float = 1.0) -> Tensor:
+    """recon_metrics through the entry point that allocates nothing: the caller brings `out` (3 floats)
+    and the partial sums go to the library's own per-GPU array instead of a workspace tensor.  For callers
+    that cannot allocate; calls that overlap in time on one GPU race on that array."""
+    _chk(recon, target, out)
+    if recon.shape != target.shape or out.numel() < 3:
+        raise RuntimeError("recon_metrics_noalloc: recon/target shapes differ or out has fewer than 3 elements")
+    B, T = recon.shape[:2]
+    P = recon[0, 0].numel()
+    with torch.cuda.device(recon.device):
+        check(lib.dvae_recon_metrics_noalloc_f32(_p(recon), _p(target), _p(out), B, T, P, float(max_val),
+                                                 torch.cuda.current_stream().cuda_stream), 'recon_metrics_noalloc')
+    return out
+
+
 def recon_loss_bwd(recon: Tensor, target: Tensor, gscale: Optional[Tensor], kind: int,
                    temporal_weight: float) -> Tensor:
     _chk(recon, target, gscale)

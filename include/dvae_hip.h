@@ -85,6 +85,21 @@ int dvae_recon_loss_bwd_f32(const float* recon, const float* target, const float
 int dvae_recon_metrics_f32(const float* recon, const float* target, float* out, float* ws, int64_t B,
                            int64_t T, int64_t P, float max_val, dvae_stream_t stream);
 
+/* ---- dvae_recon_metrics_f32 for callers that cannot allocate device memory (code under HIP graph
+ *      capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ *      Same arguments minus the workspace, same kernels, same results bit for bit: the per-workgroup
+ *      partial sums go to a 32 KiB array that is part of the library's device image (each GPU the
+ *      library runs on holds its own copy until the process ends), located once per device at the first
+ *      call on that device.  The call allocates and frees nothing.  It must be made with the device of
+ *      the pointers current.  Limit: B*T*P <= DVAE_NOALLOC_MAX_ELEMENTS elements per clip tensor
+ *      (-EINVAL beyond; dvae_recon_metrics_f32 has no such limit).  All calls on one GPU share that
+ *      GPU's array: calls that overlap in time on one GPU (different streams, different threads) race;
+ *      calls ordered on one stream do not.  Nothing needs clearing between calls. */
+#define DVAE_NOALLOC_MAX_ELEMENTS ((int64_t)1 << 31)
+int64_t dvae_recon_metrics_noalloc_max_elements(void);
+int dvae_recon_metrics_noalloc_f32(const float* recon, const float* target, float* out, int64_t B, int64_t T,
+                                   int64_t P, float max_val, dvae_stream_t stream);
+
 /* ---- reparameterisation (models/encoders.py:207-214): z = mu + eps*exp(0.5*logvar), n elements. */
 int dvae_reparam_fwd_f32(const float* mu, const float* logvar, const float* eps, float* z, int64_t n,
                          dvae_stream_t stream);
