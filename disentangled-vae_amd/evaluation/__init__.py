@@ -1,2 +1,3 @@
 """Evaluation helpers that stay on the device (reference package: evaluation/)."""
-from .metrics import mse, psnr, reconstruction_metrics, temporal_consistency  # noqa: F401
+from .metrics import (compare_models, computational_efficiency, generation_diversity, mse, psnr,  # noqa: F401
+                      reconstruction_metrics, temporal_consistency)

@@ -291,6 +291,84 @@ def baseline_decode(sd: SD, z: Tensor, T: int, training: bool, new_stats: Option
 
 
 # ---------------------------------------------------------------------------
+# the methods evaluation code and notebooks call besides forward()
+# (all under no_grad in the reference: reparameterize returns mu; BatchNorm follows `training`)
+# ---------------------------------------------------------------------------
+def disentangled_encode(sd: SD, video: Tensor, training: bool, lstm_layers: int = 1, bidirectional: bool = True,
+                        aggregation: str = 'mean', new_stats: Optional[SD] = None):
+    """DisentangledVAE.encode under no_grad; models/disentangled_vae.py:82-91 -> (mu_content, mu_motion)."""
+    B, T = video.shape[:2]
+    mean, diff = split_mean_diff(video)
+    frame = mean if aggregation == 'mean' else video[:, T // 2]
+    mu_c, _ = vae_head(cnn_encoder(frame, sd, 'content_encoder.cnn_encoder', training, new_stats), sd,
+                       'content_encoder.vae_head')
+    feat_m = cnn_encoder(diff.reshape(B * (T - 1), *diff.shape[2:]), sd, 'motion_encoder.cnn_encoder', training,
+                         new_stats).reshape(B, T - 1, -1)
+    mu_m, _ = vae_head(lstm_encoder(feat_m, sd, 'motion_encoder.lstm.lstm', lstm_layers, bidirectional), sd,
+                       'motion_encoder.vae_head')
+    return mu_c, mu_m
+
+
+def _running(sd: SD, new_stats: Optional[SD]) -> SD:
+    """sd with the BatchNorm buffers a previous training-mode call has produced."""
+    if not new_stats:
+        return sd
+    out = dict(sd)
+    out.update(new_stats)
+    return out
+
+
+def swap_content(sd: SD, video_content: Tensor, video_motion: Tensor, training: bool = False,
+                 new_stats: Optional[SD] = None, **kw) -> Tensor:
+    """DisentangledVAE.swap_content; models/disentangled_vae.py:139-149: content of the first clip, motion of
+    the second.  Each encode() runs BOTH encoders, so in training mode the BatchNorm buffers move three
+    times (two encodes, one decode), in this order."""
+    ns = new_stats if new_stats is not None else {}
+    z_c, _ = disentangled_encode(sd, video_content, training, new_stats=ns, **kw)
+    _, z_m = disentangled_encode(_running(sd, ns), video_motion, training, new_stats=ns, **kw)
+    return disentangled_decode(_running(sd, ns), z_c, z_m, video_content.shape[1], training,
+                               kw.get('lstm_layers', 1), ns)
+
+
+def _alpha_mix(a: Tensor, b: Tensor, num_steps: int) -> Tensor:
+    """(1 - alpha) a + alpha b for alpha in linspace(0, 1, num_steps), rows concatenated
+    (models/disentangled_vae.py:170-175)."""
+    alphas = torch.linspace(0, 1, num_steps, dtype=a.dtype)
+    return torch.cat([(1 - al) * a + al * b for al in alphas], dim=0)
+
+
+def interpolate_content(sd: SD, video1: Tensor, video2: Tensor, num_steps: int = 10,
+                        use_motion_from: str = 'first', **kw) -> Tensor:
+    """models/disentangled_vae.py:158-181 (eval mode; single-clip inputs)."""
+    c1, m1 = disentangled_encode(sd, video1, False, **kw)
+    c2, m2 = disentangled_encode(sd, video2, False, **kw)
+    z_m = (m1 if use_motion_from == 'first' else m2).expand(num_steps, -1)
+    return disentangled_decode(sd, _alpha_mix(c1, c2, num_steps), z_m, video1.shape[1], False,
+                               kw.get('lstm_layers', 1))
+
+
+def interpolate_motion(sd: SD, video1: Tensor, video2: Tensor, num_steps: int = 10,
+                       use_content_from: str = 'first', **kw) -> Tensor:
+    """models/disentangled_vae.py:183-206."""
+    c1, m1 = disentangled_encode(sd, video1, False, **kw)
+    c2, m2 = disentangled_encode(sd, video2, False, **kw)
+    z_c = (c1 if use_content_from == 'first' else c2).expand(num_steps, -1)
+    return disentangled_decode(sd, z_c, _alpha_mix(m1, m2, num_steps), video1.shape[1], False,
+                               kw.get('lstm_layers', 1))
+
+
+def tuple_interpolate(kind: str, sd: SD, video1: Tensor, video2: Tensor, num_steps: int = 10,
+                      lstm_layers: int = 1) -> Tensor:
+    """BaselineVAE.interpolate / LSTMVAE.interpolate; models/baseline_vae.py:166-191, models/lstm_vae.py:130-149."""
+    fwd = (lambda v: baseline_forward(sd, v, None, False)) if kind == 'baseline' else \
+        (lambda v: lstm_vae_forward(sd, v, None, False, lstm_layers))
+    z1, z2 = fwd(video1)[1], fwd(video2)[1]
+    z = _alpha_mix(z1, z2, num_steps)
+    T = video1.shape[1]
+    return baseline_decode(sd, z, T, False) if kind == 'baseline' else lstm_vae_decode(sd, z, T, False, lstm_layers)
+
+
+# ---------------------------------------------------------------------------
 # losses
 # ---------------------------------------------------------------------------
 def recon_term(recon: Tensor, target: Tensor, kind: str) -> Tensor:
