@@ -29,7 +29,16 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # v_mfma_f32_32x32x16_bf16, dense
 PEAK_HBM_GBS = 8000.0
+# algorithmic GFLOP per clip (conv, transposed conv, Linear and LSTM products only; forward x 3 for a
+# training step) of the three JSON configurations at 20 frames of 64 x 64
+GFLOP_PER_CLIP = {'disentangled_simple.json': (1.524, 4.571), 'lstm_simple.json': (2.397, 7.191),
+                  'small_baseline.json': (0.558, 1.675)}
+PRECISION_LABEL = {'fp32': ('f32', 'fp32 MFMA'),
+                   'bf16': ('bf16', 'bf16 MFMA operands, fp32 accumulate and storage'),
+                   'fp32_split': ('f32', 'fp32 products from a three-term bf16 split of each operand '
+                                         '(Linear layers), fp32 MFMA elsewhere')}
 
 
 def load_config(name):
@@ -76,211 +85,58 @@ def loss_call(kind, losses_mod, out, video, t, beta):
 
 
 # --------------------------------------------------------------------------------------------
-# per-kernel timing: events around every launch of the GEMM-shaped and streaming entry points
+# per-kernel timing: the library's own launch trace (two events around every kernel launch, on the
+# stream it is launched on), grouped by kernel symbol as a profiler prints it
 # --------------------------------------------------------------------------------------------
-class KernelTimer:
-    def __init__(self, ops):
-        self.ops = ops
-        self.records = []          # (key, start_event, end_event, work, unit)
-        self.saved = {}
-        self.shapes = []           # DVAE_BENCH_DEBUG: tensor-argument shapes of every timed launch
+def short_symbol(name):
+    """a demangled kernel name without its parameter list and return type (the key of the tables here
+    and of profiles/*pmc_traffic.json)"""
+    import re
+    return re.sub(r'\(.*\)$', '', name).replace('void ', '').strip()
 
-    def _wrap(self, name, keyfn):
-        orig = getattr(self.ops, name)
-        self.saved[name] = orig
 
-        def wrapped(*a, **k):
-            key, work, unit = keyfn(*a, **k)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = orig(*a, **k)
-            e.record()
-            self.records.append((key, s, e, work, unit))
-            if os.environ.get('DVAE_BENCH_DEBUG'):
-                self.shapes.append([tuple(t.shape) for t in a if torch.is_tensor(t)])
-            return r
-        setattr(self.ops, name, wrapped)
-
-    def install(self):
-        def tile(c, rows=None, phases=1, stats=True):
-            """tile the launcher picks: by output channels, narrowed while fewer than 256 workgroups; a
-            layer without statistics whose 128-wide tiles end in a partly filled round of the 512
-            workgroup slots finishes with a second launch of 64-wide tiles"""
-            bn = 128 if c > 64 else (64 if c > 32 else 32)
-            if rows is not None:
-                row_tiles = -(-rows // 128) * phases
-                while bn > 32 and row_tiles * -(-c // bn) < 256:
-                    bn //= 2
-                tiles = row_tiles * -(-c // 128)
-                if bn == 128 and not stats and tiles >= 512 and 512 <= 5 * (tiles % 512) and 10 * (tiles % 512) <= 3584:
-                    return 'T128+T64'
-            return f'T{bn}'
-
-        def conv_key(x, sc, sh, act, wp, stats):
-            N, H, W, Cin = x.shape
-            Cout = wp.shape[0]
-            if Cin == 1:        # sixteen taps deep: bound by the write of the output
-                return "conv_c1_kernel", float(x.numel() * 4 + N * (H // 2) * (W // 2) * Cout * 4), 'byte'
-            fl = 2.0 * N * (H // 2) * (W // 2) * Cout * 16 * Cin
-            if (Cin, Cout) in ((32, 64), (16, 32)) and 32 <= W <= 64:     # few channels: rows through an LDS ring
-                return f"conv_rows_kernel<{Cin},{Cout}>", fl, 'flop'
-            return f"conv_fwd_kernel<{tile(Cout, N * (H // 2) * (W // 2), 1, stats)},conv>", fl, 'flop'
-
-        def conv_bn_key(x, wp, bn_y, aff):
-            key, work, unit = conv_key(x, None, None, 0, wp, True)
-            if unit == 'byte':
-                return key + ',bnstat', work + float(bn_y.numel() * 4), unit
-            return key[:-1] + ',bnstat>', work, unit
-
-        def conv_bnin_key(du_in, in_y, in_aff, ca, cb, wp, bn_y, bn_aff):
-            key, work, unit = conv_key(du_in, None, None, 0, wp, True)
-            return key[:-1] + ',bnstat,bnin>', work, unit
-
-        def deconv_bn_key(x, wp, bn_y, aff):
-            key, work, unit = deconv_key(x, None, None, 0, wp, True)
-            return key[:-1] + ',bnstat>', work, unit
-
-        def deconv_key(x, sc, sh, act, wp, stats):
-            N, H, W, Cin = x.shape
-            Cout = wp.shape[1]
-            fl = 2.0 * N * 4 * H * W * Cout * 4 * Cin
-            if (Cin, Cout, W) == (128, 64, 8):
-                return "deconv_rows8_kernel<128>", fl, 'flop'
-            if (Cin, Cout) in ((32, 16), (64, 32)) and 16 <= W <= 32:   # few channels: rows through an LDS ring
-                return f"deconv_rows_kernel<{Cin},{Cout}>", fl, 'flop'
-            return f"conv_fwd_kernel<{tile(Cout, N * H * W, 4, stats)},deconv>", fl, 'flop'
-
-        def wgrad_key(P, ps, ph, pa, Q, qs, qh, qa):
-            N, Hs, Ws, C1 = P.shape
-            C2 = Q.shape[3]
-            fl = 2.0 * N * Hs * Ws * C1 * 16 * C2
-            if (C1, C2, Ws, Hs) == (256, 128, 4, 4) and N >= 32:
-                return "wgrad_img4_kernel", fl, 'flop'
-            if (C1, C2, Ws) == (128, 64, 8):
-                return "wgrad_rows8_kernel", fl, 'flop'
-            if (C1, C2) in ((64, 32), (32, 16)) and Ws in (16, 32):       # few channels: rows through LDS rings
-                return f"wgrad_rows_kernel<{C1},{C2}>", fl, 'flop'
-            if C2 == 1:
-                var = 'T128x32,c1'
-            else:
-                var = 'T32x128' if C1 <= 32 else ('T64x128' if C1 <= 64 else 'T128x128')
-            return f"conv_wgrad_kernel<{var}>", fl, 'flop'
-
-        def gemm_key(kind):
-            def f(a, b, *rest, **kw):
-                if kind == 'nt':
-                    M, K = a.shape
-                    N = b.shape[0]
-                elif kind == 'nn':
-                    M, K = a.shape
-                    N = b.shape[1]
-                else:
-                    K, M = a.shape
-                    N = b.shape[1]
-                tiles16 = -(-M // 16) * -(-N // 16)      # the launcher's rule for its small-product kernel
-                name = 'small_gemm_kernel' if tiles16 <= 1024 and tiles16 * K <= (1 << 20) else 'gemm_kernel'
-                return f"{name}<{kind}>", 2.0 * M * N * K, 'flop'
-            return f
-
-        def final_key(x, sc, sh, act, w, b, oa):
-            return "deconv_final_kernel", float(x.numel() * 4 + x.shape[0] * 4 * x.shape[1] * x.shape[2] * 4), 'byte'
-
-        def split_key(v):
-            return "split_mean_diff_kernel", float(v.numel() * 4 * 2), 'byte'
-
-        def bn_bwd_key(du, y, sc, sh, mean, invstd, gamma, partials=None):
-            if partials is not None:       # statistics came from the producing kernel: 2 reads + 1 write
-                return "bn_bwd (apply)", float(y.numel() * 4 * 3), 'byte'
-            return "bn_bwd (reduce+apply)", float(y.numel() * 4 * 5), 'byte'    # 2 reads + 2 reads + 1 write
-
-        def loss_fwd_key(recon, target, *r):
-            return "recon_loss_fwd_kernel", float(recon.numel() * 4 * 2), 'byte'
-
-        def loss_bwd_key(recon, target, *r):
-            return "recon_loss_bwd_kernel", float(recon.numel() * 4 * 3), 'byte'
-
-        def lstm_key(*a):
-            h_out = a[9]
-            B, H = h_out.shape
-            x = a[1]
-            K = H + (0 if x is None else x.shape[1])
-            return "lstm_step_fwd_kernel", 2.0 * B * 4 * H * K, 'flop'
-
-        def skinny_key(a, wt, out, acc):
-            B, K = a.shape
-            return "skinny_gemm_nt_kernel", 2.0 * B * wt.shape[0] * K, 'flop'
-
-        self._wrap('conv4s2_fwd', conv_key)
-        self._wrap('deconv4s2_fwd', deconv_key)
-        self._wrap('conv4s2_dgrad_bnstat', conv_bn_key)
-        self._wrap('deconv4s2_dgrad_bnstat', deconv_bn_key)
-        self._wrap('conv4s2_dgrad_bnstat_bnin', conv_bnin_key)
-
-        def deconv_bnin_key(du_in, in_y, in_aff, ca, cb, wp, bn_y, bn_aff):
-            key, work, unit = deconv_key(du_in, None, None, 0, wp, True)
-            return key[:-1] + ',bnstat,bnin>', work, unit
-
-        def wgrad_bnq_key(P, ps, ph, pa, du, q_y, q_aff, ca, cb):
-            key, work, unit = wgrad_key(P, ps, ph, pa, du, None, None, 0)
-            return key + ',bnq', work, unit
-
-        def wgrad_bnp_key(du, p_y, p_aff, ca, cb, Q):
-            key, work, unit = wgrad_key(du, None, None, 0, Q, None, None, 0)
-            return key[:-1] + ',bnp>', work, unit
-
-        self._wrap('deconv4s2_dgrad_bnstat_bnin', deconv_bnin_key)
-        self._wrap('conv4s2_wgrad_bnq', wgrad_bnq_key)
-        self._wrap('conv4s2_wgrad_bnp', wgrad_bnp_key)
-        self._wrap('conv4s2_wgrad', wgrad_key)
-        self._wrap('gemm_nt', gemm_key('nt'))
-        self._wrap('gemm_nn', gemm_key('nn'))
-        self._wrap('gemm_tn', gemm_key('tn'))
-        self._wrap('deconv4s2_final_fwd', final_key)
-        self._wrap('split_mean_diff', split_key)
-        self._wrap('bn_bwd', bn_bwd_key)
-        self._wrap('recon_loss_fwd', loss_fwd_key)
-        self._wrap('recon_loss_bwd', loss_bwd_key)
-        self._wrap('lstm_step_fwd', lstm_key)
-        self._wrap('skinny_gemm_nt', skinny_key)
-        self._wrap('lstm_bwd_step', lambda dg_t, wt, *r: ('lstm_bwd_step_kernel', 2.0 * dg_t.shape[0] * wt.shape[0] * dg_t.shape[1], 'flop'))
-
-    def remove(self):
-        for n, f in self.saved.items():
-            setattr(self.ops, n, f)
-
-    def summary(self, steps):
-        """One row per kernel group.  Every step issues the same launches in the same order, so the
-        records split into `steps` equal runs; a group's time per step is the MEDIAN over the steps of
-        its per-step sum (one stalled launch, e.g. behind an allocation, does not move it)."""
-        torch.cuda.synchronize()
-        per = len(self.records) // steps
-        if per * steps != len(self.records):
-            raise RuntimeError(f"{len(self.records)} timed launches do not split into {steps} equal steps")
-        agg = {}
-        for i, (key, s, e, work, unit) in enumerate(self.records):
-            a = agg.setdefault(key, {'ms': [0.0] * steps, 'launches': 0, 'work': 0.0, 'unit': unit})
-            ms = s.elapsed_time(e)
-            a['ms'][i // per] += ms
-            a['launches'] += 1
-            a['work'] += work
-            if os.environ.get('DVAE_BENCH_DEBUG'):
-                rate = work / ms / (1e9 if unit == 'flop' else 1e6)
-                print('launch', i // per, key, round(ms * 1e3, 1), 'us', round(rate, 1),
-                      'TFLOP/s' if unit == 'flop' else 'GB/s', self.shapes[i], file=sys.stderr)
-        rows = []
-        for key, a in agg.items():
-            ms = sorted(a['ms'])[steps // 2]
-            sec, work, launches = ms / 1e3, a['work'] / steps, a['launches'] // steps
-            if a['unit'] == 'flop':
-                ach, peak, u, bound = work / sec / 1e12, PEAK_FP32_MFMA_TFLOPS, 'TFLOP/s', 'mfma'
-            else:
-                ach, peak, u, bound = work / sec / 1e9, PEAK_HBM_GBS, 'GB/s', 'hbm'
-            rows.append({'kernel': key, 'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': u,
-                         'frac': round(ach / peak, 4), 'ms_per_step': round(ms, 4),
-                         'launches_per_step': launches,
-                         'avg_launch_us': round(ms * 1e3 / launches, 2)})
-        rows.sort(key=lambda r: -r['ms_per_step'])
-        return rows
+def trace_steps(step_fn, nsteps, peak_tflops):
+    """Runs nsteps eager steps under the library's launch trace.  One row per kernel symbol: time per step
+    = MEDIAN over the steps of the symbol's per-step sum (every step issues the same launches in the same
+    order, so the records split into nsteps equal runs); achieved = declared algorithmic work / time."""
+    from hipvae import ops
+    ops.trace_begin(1 << 16)
+    for i in range(nsteps):
+        step_fn(i)
+    torch.cuda.synchronize()
+    recs = ops.trace_collect()
+    per = len(recs) // nsteps
+    if per * nsteps != len(recs):
+        raise RuntimeError(f"{len(recs)} traced launches do not split into {nsteps} equal steps")
+    agg = {}
+    for i, (name, ms, work, unit) in enumerate(recs):
+        key = short_symbol(name)
+        a = agg.setdefault(key, {'ms': [0.0] * nsteps, 'launches': 0, 'flop': 0.0, 'byte': 0.0})
+        a['ms'][i // per] += ms
+        a['launches'] += 1
+        if unit == 1:
+            a['flop'] += work
+        elif unit == 2:
+            a['byte'] += work
+    rows = []
+    for key, a in agg.items():
+        ms = sorted(a['ms'])[nsteps // 2]
+        launches = a['launches'] // nsteps
+        row = {'kernel': key, 'ms_per_step': round(ms, 4), 'launches_per_step': launches,
+               'avg_launch_us': round(ms * 1e3 / max(launches, 1), 2)}
+        if a['flop'] > 0:
+            ach = a['flop'] / nsteps / (ms / 1e3) / 1e12
+            row.update(bound='mfma', achieved=round(ach, 2), peak=peak_tflops, unit='TFLOP/s',
+                       frac=round(ach / peak_tflops, 4), work_per_launch=a['flop'] / a['launches'])
+        elif a['byte'] > 0:
+            ach = a['byte'] / nsteps / (ms / 1e3) / 1e9
+            row.update(bound='hbm', achieved=round(ach, 2), peak=PEAK_HBM_GBS, unit='GB/s',
+                       frac=round(ach / PEAK_HBM_GBS, 4), work_per_launch=a['byte'] / a['launches'])
+        else:
+            row.update(bound=None, achieved=None, peak=None, unit=None, frac=None, work_per_launch=0.0)
+        rows.append(row)
+    rows.sort(key=lambda r: -r['ms_per_step'])
+    return rows
 
 
 def pmc_traffic(label):
@@ -301,8 +157,10 @@ def pmc_traffic(label):
 
 
 # --------------------------------------------------------------------------------------------
-def cpu_baseline(kind, cfg, steps=3, batch=32):
-    """The CPU oracle's training step timed on the host cores (bounded sample)."""
+def cpu_baseline(kind, cfg, steps=10, warmup=3, batch=32):
+    """The CPU oracle (oracle/vae_oracle.py, a restatement of the reference pinned to the reference's own
+    vectors) timed on the host cores: training step = forward + loss + backward + clip + Adam; inference =
+    eval-mode forward.  3 warm-up + 10 timed steps each, median."""
     from oracle import vae_oracle as O
     import models
     torch.manual_seed(0)
@@ -319,15 +177,24 @@ def cpu_baseline(kind, cfg, steps=3, batch=32):
     layers = kw.get('lstm_layers', 1)
     opt = {}
     times = []
-    for i in range(steps + 1):
+    for i in range(warmup + steps):
         t0 = time.perf_counter()
         sd, opt, _, _ = O.train_step(kind, sd, opt, video, eps, 4.0, t, t['learning_rate'], lstm_layers=layers,
                                      bidirectional=kw.get('bidirectional', True))
         times.append(time.perf_counter() - t0)
-    med = sorted(times[1:])[len(times[1:]) // 2]
+    med = sorted(times[warmup:])[steps // 2]
+    itimes = []
+    with torch.no_grad():
+        for i in range(warmup + steps):
+            t0 = time.perf_counter()
+            O.model_forward(kind, sd, video, [None, None], False, lstm_layers=layers)
+            itimes.append(time.perf_counter() - t0)
+    imed = sorted(itimes[warmup:])[steps // 2]
     return {'value': round(batch / med, 2), 'unit': 'clips/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{steps} training steps (after 1 warm-up) of the CPU oracle, batch {batch}, fp32, '
-                      f'median {med * 1e3:.0f} ms/step'}
+            'sample': f'{steps} training steps (after {warmup} warm-up) of the CPU oracle, batch {batch}, fp32, '
+                      f'median {med * 1e3:.0f} ms/step; inference leg: {steps} eval-mode forwards, median '
+                      f'{imed * 1e3:.0f} ms',
+            'inference': {'value': round(batch / imed, 2), 'unit': 'clips/s'}}
 
 
 def main():
@@ -341,7 +208,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-table', action='store_true')
     ap.add_argument('--bucket-mb', type=float, default=16.0)
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'fp32_split'],
                     help='operand precision of the MFMA kernels for the headline number')
     ap.add_argument('--no-extras', action='store_true', help='skip the inference and bf16-variant measurements')
     ap.add_argument('--host-batches', default='', choices=['', 'serial', 'prefetch'],
@@ -484,14 +351,15 @@ def main():
                 return inner(i)
     elapsed, last = measure(step, args.steps, args.warmup)
     value = world * B * args.steps / elapsed
-    prec_label = 'fp32 MFMA' if args.precision == 'fp32' else 'bf16 MFMA operands, fp32 accumulate and storage'
+    dtype_label, prec_label = PRECISION_LABEL[args.precision]
+    peak_tflops = PEAK_BF16_MFMA_TFLOPS if args.precision == 'bf16' else PEAK_FP32_MFMA_TFLOPS
 
     result = {
         'metric': ('training' if args.mode == 'train' else 'inference') +
                   ' clips/sec (20x64x64 Moving MNIST) at 1/2/4/8 MI355X vs host CPU',
         'value': round(value, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': dtype_label, 'data': 'synthetic',
         'config': {'workload': f"{cfg['name']} ({args.config}) {args.mode} step, beta=4, {T}x{size}x{size} clips, "
                                f"batch {B}/GPU, {prec_label}, {('batches from pinned host memory (' + args.host_batches + '), ') if args.host_batches else ''}{('hipGraph replay' + (' (backward graph, one all-reduce, update graph)' if use_dp else '')) if use_graph else 'eager launches'}",
                    'global_batch': B * world, 'params': n_params,
@@ -500,25 +368,35 @@ def main():
     if args.mode == 'train':
         result['loss'] = round(float(last['total_loss'].item()), 3)
 
-    if rank == 0 and world == 1 and not args.no_kernel_table and args.precision == 'fp32':
+    if use_dp:
+        result['rccl_world_size'] = dist.get_world_size()
+        result['config']['collective'] = ('one all-reduce (AVG) of the flat fp32 gradient buffer per step over RCCL'
+                                          if use_graph else 'bucketed all-reduces (AVG) over RCCL, overlapped with backward')
+    gf = GFLOP_PER_CLIP.get(args.config)
+    whole = None
+    if gf is not None and size == 64 and T == 20:
+        tfl = gf[1 if args.mode == 'train' else 0] * B * world / (elapsed / args.steps) / 1e3
+        whole = {'achieved': round(tfl, 2), 'peak': peak_tflops * world, 'unit': 'TFLOP/s',
+                 'frac': round(tfl / (peak_tflops * world), 4),
+                 'gflop_per_clip': gf[1 if args.mode == 'train' else 0]}
+    if rank == 0 and world == 1 and not args.no_kernel_table:
         step = train_step if args.mode == 'train' else infer_step      # kernels are timed on eager launches
         step(0)                      # untimed: the eager path's buffers come out of the allocator's cache afterwards
-        kt = KernelTimer(ops)
-        kt.install()
-        nprof = 5
-        for i in range(nprof):
-            step(i)
-        rows = kt.summary(nprof)
-        kt.remove()
+        rows = trace_steps(step, 5, peak_tflops)
         top = rows[0]
         traffic, traffic_src = pmc_traffic(top['kernel'])
         result['roofline'] = {'kernel': top['kernel'], 'bound': top['bound'], 'achieved': top['achieved'],
                               'peak': top['peak'], 'unit': top['unit'], 'frac': top['frac'], 'traffic': traffic,
-                              'traffic_source': traffic_src,
+                              'traffic_source': traffic_src, 'algorithmic_work_per_launch': top['work_per_launch'],
                               'avg_launch_us': top['avg_launch_us'], 'launches_per_step': top['launches_per_step'],
-                              'ms_per_step': top['ms_per_step']}
-        result['kernels'] = [{k: r[k] for k in ('kernel', 'bound', 'achieved', 'unit', 'frac', 'ms_per_step')}
-                             for r in rows[:12]]
+                              'ms_per_step': top['ms_per_step'], 'whole_step': whole}
+        traced_ms = sum(r['ms_per_step'] for r in rows)
+        result['kernels'] = [{k: r[k] for k in ('kernel', 'bound', 'achieved', 'unit', 'frac', 'ms_per_step',
+                                                'launches_per_step', 'avg_launch_us')} for r in rows[:16]]
+        result['kernels_note'] = (f'{len(rows)} kernel symbols of this library, {round(traced_ms, 3)} ms per eager step '
+                                  f'in all; the first {min(16, len(rows))} listed')
+    elif whole is not None:
+        result['roofline'] = {'whole_step': whole}
     if args.mode == 'train' and not args.no_extras and world == 1:
         # the same job's inference rate (eval-mode forward, no_grad) and its bf16-MFMA variant
         model.eval()
@@ -544,6 +422,28 @@ def main():
                             'bf16 MFMA products of a three-term operand split (fp32-level error); not the headline '
                             'value'}
             ops.set_precision('fp32')
+        if args.config == 'disentangled_simple.json' and args.precision == 'fp32':
+            # BASELINE configurations 2 and 3 (batch 32 on one GPU, fp32) and the small baseline beside them
+            others = {}
+            for cfg_name in ('disentangled_simple.json', 'lstm_simple.json', 'small_baseline.json'):
+                c2 = load_config(cfg_name)
+                k2, t2 = c2['model']['model_type'], c2['training']
+                torch.manual_seed(0)
+                m2 = models.get_model(k2, **model_kwargs(c2)).to(dev).train()
+                o2 = FusedAdam(m2.parameters(), lr=t2['learning_rate'], betas=(t2['beta1'], t2['beta2']),
+                               weight_decay=t2['weight_decay'])
+                r2 = [synthetic_clips(32, 20, 64, 7000 + i).to(dev) for i in range(4)]
+                from hipvae.graph import GraphedTrainStep
+                g2 = GraphedTrainStep(m2, o2, lambda mm, v, k2=k2, t2=t2: loss_call(k2, L, mm(v), v, t2, beta), r2[0],
+                                      gradient_clip=t2['gradient_clip'])
+                el, _ = measure(lambda i: g2(r2[i % 4]), args.steps, args.warmup)
+                ms2 = el / args.steps * 1e3
+                gf2 = GFLOP_PER_CLIP[cfg_name][1]
+                others[cfg_name] = {'batch': 32, 'ms_per_step': round(ms2, 3), 'value': round(32 / ms2 * 1e3, 1),
+                                    'unit': 'clips/s',
+                                    'whole_step_frac': round(gf2 * 32 / ms2 / PEAK_FP32_MFMA_TFLOPS, 4)}
+                del g2, m2, o2, r2
+            result['batch32_configs'] = others
     if use_dp:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == 'train':

@@ -40,6 +40,27 @@ int dvae_mfma_precision();
     }                                                                        \
   } while (0)
 
+// Launch tracing (see trace.hip): every launch of the library goes through DVAE_LAUNCH; a launcher may
+// declare the algorithmic work of its next launch (FLOPs of a GEMM-shaped kernel, bytes an HBM-bound
+// kernel has to move) with dvae_trace_work just before it.
+#define DVAE_UNIT_NONE 0
+#define DVAE_UNIT_FLOP 1
+#define DVAE_UNIT_BYTE 2
+extern int g_dvae_trace_on;
+void dvae_trace_pre(hipStream_t s);
+void dvae_trace_post(const void* fn, hipStream_t s);
+void dvae_trace_work(double work, int unit);
+#define DVAE_WORK(work, unit)                               \
+  do {                                                      \
+    if (g_dvae_trace_on) dvae_trace_work((double)(work), unit); \
+  } while (0)
+#define DVAE_LAUNCH(kernel, grid, block, lds, stream, ...)                 \
+  do {                                                                     \
+    if (g_dvae_trace_on) dvae_trace_pre(stream);                           \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);     \
+    if (g_dvae_trace_on) dvae_trace_post((const void*)(kernel), stream);   \
+  } while (0)
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 __device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : x * LRELU_SLOPE; }

@@ -55,7 +55,7 @@ extern "C" int dvae_pack_conv_w_f32(const float* w, float* wp, int64_t A, int64_
   DVAE_REQUIRE(A > 0 && Bc > 0, "pack_conv_w: empty");
   int64_t nb = ceil_div64(A * Bc * 16, 256);
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(pack_conv_w_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), w, wp, A, Bc);
+  DVAE_LAUNCH(pack_conv_w_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), w, wp, A, Bc);
   DVAE_LAUNCH_CHECK("pack_conv_w");
   return 0;
 }
@@ -64,7 +64,7 @@ extern "C" int dvae_pack_deconv_w_f32(const float* w, float* wp, int64_t Kc, int
   DVAE_REQUIRE(Kc > 0 && Nc > 0, "pack_deconv_w: empty");
   int64_t nb = ceil_div64(Kc * Nc * 16, 256);
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(pack_deconv_w_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), w, wp, Kc, Nc);
+  DVAE_LAUNCH(pack_deconv_w_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), w, wp, Kc, Nc);
   DVAE_LAUNCH_CHECK("pack_deconv_w");
   return 0;
 }
@@ -1129,15 +1129,21 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     }                                                                                                \
     int gx = g.mtiles - g.mt0 < CONV_MAX_PARTS ? g.mtiles - g.mt0 : CONV_MAX_PARTS;                  \
     dim3 grid(gx * phases, (unsigned)ceil_div64(g.Cout, TILE::BN), 1);                               \
+    {                                                                                                \
+      int64_t rows_ = (int64_t)g.mtiles * TILE::BM;                                                  \
+      rows_ = (rows_ < g.M ? rows_ : g.M) - (int64_t)g.mt0 * TILE::BM;                               \
+      if (C1FLAG) DVAE_WORK(4.0 * ((double)rows_ * 4 + (double)rows_ * g.Cout), DVAE_UNIT_BYTE);     \
+      else DVAE_WORK(2.0 * (double)rows_ * phases * g.Cout * g.K, DVAE_UNIT_FLOP);                   \
+    }                                                                                                \
     if (bns && !(C1FLAG)) {                                                                          \
       if (bf)                                                                                        \
-        hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG, !(C1FLAG), !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
+        DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, !(C1FLAG), !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
       else                                                                                           \
-        hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG, false, !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
+        DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, false, !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
     } else if (bf && !(C1FLAG))                                                                      \
-      hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG, !(C1FLAG), false>), grid, dim3(256), 0, stream, g); \
+      DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, !(C1FLAG), false>), grid, dim3(256), 0, stream, g); \
     else                                                                                             \
-      hipLaunchKernelGGL((conv_fwd_kernel<TILE, MODE, C1FLAG, false, false>), grid, dim3(256), 0, stream, g); \
+      DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, false, false>), grid, dim3(256), 0, stream, g); \
   }
   int mt_begin = 0, mt_end = -1;       // M-tile range of the next LAUNCH (-1: the whole layer)
   typedef Tile<128, 128, 2, 2, true, true> T128;
@@ -1150,19 +1156,20 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     const dim3 grid((unsigned)(conv_parts_written(g.M, phases) / phases));                                \
     g.mtiles = (int)grid.x < 256 * RESIDENT ? (int)grid.x : 256 * RESIDENT;                               \
     const bool xf = g.in_scale != nullptr || g.in_act != DVAE_ACT_NONE;                                   \
+    DVAE_WORK(2.0 * (double)g.M * phases * g.Cout * g.K, DVAE_UNIT_FLOP);                                 \
     if (g.in_y != nullptr && bns)                                                                         \
-      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, false, true, true>), grid, dim3(256), 0, stream, g); \
+      DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, false, true, true>), grid, dim3(256), 0, stream, g); \
     else if (g.in_y != nullptr) {                                                                         \
       dvae_set_error("%s: a BatchNorm-backward input needs the fused statistics of the layer below", name); \
       return -EINVAL;                                                                                     \
     } else if (bns && xf)                                                                                 \
-      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, true, true, false>), grid, dim3(256), 0, stream, g); \
+      DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, true, true, false>), grid, dim3(256), 0, stream, g); \
     else if (bns)                                                                                         \
-      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, false, true, false>), grid, dim3(256), 0, stream, g); \
+      DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, false, true, false>), grid, dim3(256), 0, stream, g); \
     else if (xf)                                                                                          \
-      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, true, false, false>), grid, dim3(256), 0, stream, g); \
+      DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, true, false, false>), grid, dim3(256), 0, stream, g); \
     else                                                                                                  \
-      hipLaunchKernelGGL((deconv_rows_kernel<CI, CO, WPE, false, false, false>), grid, dim3(256), 0, stream, g); \
+      DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, false, false, false>), grid, dim3(256), 0, stream, g); \
     DVAE_LAUNCH_CHECK(name);                                                                              \
     return 0;                                                                                             \
   }
@@ -1181,10 +1188,11 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     g.mtiles = (int)gx < 128 ? (int)gx : 128;      // 4 phases x 128 = two workgroups per compute unit
     const bool xf = g.in_scale != nullptr || g.in_act != DVAE_ACT_NONE;
     const dim3 grid(gx * 4);
-    if (bns && xf) hipLaunchKernelGGL((deconv_rows8_kernel<128, 2, true, true>), grid, dim3(256), 0, stream, g);
-    else if (bns) hipLaunchKernelGGL((deconv_rows8_kernel<128, 2, false, true>), grid, dim3(256), 0, stream, g);
-    else if (xf) hipLaunchKernelGGL((deconv_rows8_kernel<128, 2, true, false>), grid, dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((deconv_rows8_kernel<128, 2, false, false>), grid, dim3(256), 0, stream, g);
+    DVAE_WORK(2.0 * (double)g.M * phases * g.Cout * g.K, DVAE_UNIT_FLOP);
+    if (bns && xf) DVAE_LAUNCH((deconv_rows8_kernel<128, 2, true, true>), grid, dim3(256), 0, stream, g);
+    else if (bns) DVAE_LAUNCH((deconv_rows8_kernel<128, 2, false, true>), grid, dim3(256), 0, stream, g);
+    else if (xf) DVAE_LAUNCH((deconv_rows8_kernel<128, 2, true, false>), grid, dim3(256), 0, stream, g);
+    else DVAE_LAUNCH((deconv_rows8_kernel<128, 2, false, false>), grid, dim3(256), 0, stream, g);
     DVAE_LAUNCH_CHECK(name);
     return 0;
   }
@@ -1196,19 +1204,20 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     g.mtiles = (int)grid.x < 256 * RESIDENT ? (int)grid.x : 256 * RESIDENT;                               \
     const size_t lds = (size_t)8 * 2 * (g.W / 2 + 1) * (CI + 4) * sizeof(float);                          \
     const bool xf = g.in_scale != nullptr || g.in_act != DVAE_ACT_NONE;                                   \
+    DVAE_WORK(2.0 * (double)g.M * g.Cout * g.K, DVAE_UNIT_FLOP);                                          \
     if (g.in_y != nullptr && bns)                                                                         \
-      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, false, true, true>), grid, dim3(CO * 4), lds, stream, g); \
+      DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, false, true, true>), grid, dim3(CO * 4), lds, stream, g); \
     else if (g.in_y != nullptr) {                                                                         \
       dvae_set_error("%s: a BatchNorm-backward input needs the fused statistics of the layer below", name); \
       return -EINVAL;                                                                                     \
     } else if (bns && xf)                                                                                 \
-      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, true, true, false>), grid, dim3(CO * 4), lds, stream, g); \
+      DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, true, true, false>), grid, dim3(CO * 4), lds, stream, g); \
     else if (bns)                                                                                         \
-      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, false, true, false>), grid, dim3(CO * 4), lds, stream, g); \
+      DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, false, true, false>), grid, dim3(CO * 4), lds, stream, g); \
     else if (xf)                                                                                          \
-      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, true, false, false>), grid, dim3(CO * 4), lds, stream, g); \
+      DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, true, false, false>), grid, dim3(CO * 4), lds, stream, g); \
     else                                                                                                  \
-      hipLaunchKernelGGL((conv_rows_kernel<CI, CO, WPE, false, false, false>), grid, dim3(CO * 4), lds, stream, g); \
+      DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, false, false, false>), grid, dim3(CO * 4), lds, stream, g); \
     DVAE_LAUNCH_CHECK(name);                                                                              \
     return 0;                                                                                             \
   }
@@ -1223,8 +1232,9 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     // one partial-statistics row per workgroup, as many rows as the caller sized the buffer for
     const dim3 grid((unsigned)conv_parts_written(g.M, 1));
 #define C1_LAUNCH(NCB)                                                                          \
-  if (bns) hipLaunchKernelGGL((conv_c1_kernel<NCB, true>), grid, dim3(256), 0, stream, g);       \
-  else hipLaunchKernelGGL((conv_c1_kernel<NCB, false>), grid, dim3(256), 0, stream, g);
+  DVAE_WORK(4.0 * ((double)g.M * 4 + (double)g.M * g.Cout * (bns ? 2 : 1)), DVAE_UNIT_BYTE);      \
+  if (bns) DVAE_LAUNCH((conv_c1_kernel<NCB, true>), grid, dim3(256), 0, stream, g);       \
+  else DVAE_LAUNCH((conv_c1_kernel<NCB, false>), grid, dim3(256), 0, stream, g);
     if (g.Cout <= 16) {
       C1_LAUNCH(1)
     } else if (g.Cout <= 32) {
@@ -2281,15 +2291,17 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
                                   aligned16(q_a) && aligned16(q_b) && aligned16(dx_out)),
                "conv4s2_wgrad: a BatchNorm-backward Q is only taken where dvae_conv4s2_wgrad_bnq_supported says so, "
                "with y, scale, shift, A, B and dx_out, 16-byte aligned");
+  if (C2 == 1) DVAE_WORK(4.0 * ((double)g.Mtot * C1 + (double)g.Mtot * 4), DVAE_UNIT_BYTE);       // streams P (and Q) once
+  else DVAE_WORK(2.0 * (double)g.Mtot * C1 * 16 * C2, DVAE_UNIT_FLOP);
   if (p.bm == -3) {
     DVAE_REQUIRE((!p_scale || (aligned16(p_scale) && aligned16(p_shift))) && (!q_scale || (aligned16(q_scale) && aligned16(q_shift))),
                  "conv4s2_wgrad: scale/shift vectors must be 16-byte aligned");
     const dim3 grid((unsigned)p.split * 16);
     const bool xp = p_scale != nullptr || p_act != DVAE_ACT_NONE, xq = q_scale != nullptr || q_act != DVAE_ACT_NONE;
-    if (xp && xq) hipLaunchKernelGGL((wgrad_img4_kernel<true, true>), grid, dim3(256), 0, s, g);
-    else if (xp) hipLaunchKernelGGL((wgrad_img4_kernel<true, false>), grid, dim3(256), 0, s, g);
-    else if (xq) hipLaunchKernelGGL((wgrad_img4_kernel<false, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((wgrad_img4_kernel<false, false>), grid, dim3(256), 0, s, g);
+    if (xp && xq) DVAE_LAUNCH((wgrad_img4_kernel<true, true>), grid, dim3(256), 0, s, g);
+    else if (xp) DVAE_LAUNCH((wgrad_img4_kernel<true, false>), grid, dim3(256), 0, s, g);
+    else if (xq) DVAE_LAUNCH((wgrad_img4_kernel<false, true>), grid, dim3(256), 0, s, g);
+    else DVAE_LAUNCH((wgrad_img4_kernel<false, false>), grid, dim3(256), 0, s, g);
   } else if (p.bm == -2) {
     DVAE_REQUIRE(Hs >= 2, "conv4s2_wgrad: Hs must be at least 2 at this shape");
     DVAE_REQUIRE((!p_scale || (aligned16(p_scale) && aligned16(p_shift))) && (!q_scale || (aligned16(q_scale) && aligned16(q_shift))),
@@ -2297,12 +2309,12 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
     const dim3 grid((unsigned)p.split * 4);
     const bool xp = p_scale != nullptr || p_act != DVAE_ACT_NONE, xq = q_scale != nullptr || q_act != DVAE_ACT_NONE;
     if (g.q_y != nullptr) {
-      if (xp) hipLaunchKernelGGL((wgrad_rows8_kernel<true, false, true>), grid, dim3(256), 0, s, g);
-      else hipLaunchKernelGGL((wgrad_rows8_kernel<false, false, true>), grid, dim3(256), 0, s, g);
-    } else if (xp && xq) hipLaunchKernelGGL((wgrad_rows8_kernel<true, true, false>), grid, dim3(256), 0, s, g);
-    else if (xp) hipLaunchKernelGGL((wgrad_rows8_kernel<true, false, false>), grid, dim3(256), 0, s, g);
-    else if (xq) hipLaunchKernelGGL((wgrad_rows8_kernel<false, true, false>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((wgrad_rows8_kernel<false, false, false>), grid, dim3(256), 0, s, g);
+      if (xp) DVAE_LAUNCH((wgrad_rows8_kernel<true, false, true>), grid, dim3(256), 0, s, g);
+      else DVAE_LAUNCH((wgrad_rows8_kernel<false, false, true>), grid, dim3(256), 0, s, g);
+    } else if (xp && xq) DVAE_LAUNCH((wgrad_rows8_kernel<true, true, false>), grid, dim3(256), 0, s, g);
+    else if (xp) DVAE_LAUNCH((wgrad_rows8_kernel<true, false, false>), grid, dim3(256), 0, s, g);
+    else if (xq) DVAE_LAUNCH((wgrad_rows8_kernel<false, true, false>), grid, dim3(256), 0, s, g);
+    else DVAE_LAUNCH((wgrad_rows8_kernel<false, false, false>), grid, dim3(256), 0, s, g);
   } else if (p.bm == -1) {
     DVAE_REQUIRE((!p_scale || (aligned16(p_scale) && aligned16(p_shift))) && (!q_scale || (aligned16(q_scale) && aligned16(q_shift))),
                  "conv4s2_wgrad: scale/shift vectors must be 16-byte aligned");
@@ -2311,10 +2323,10 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
 #define WGR_LAUNCH(A, B)                                                                                  \
   {                                                                                                       \
     const size_t ldsb = (size_t)(4 * Ws * (A + 4) + 8 * (2 * Ws + 2) * (B + 2)) * sizeof(float);          \
-    if (xp && xq) hipLaunchKernelGGL((wgrad_rows_kernel<A, B, 2, true, true>), grid, dim3(256), ldsb, s, g);        \
-    else if (xp) hipLaunchKernelGGL((wgrad_rows_kernel<A, B, 2, true, false>), grid, dim3(256), ldsb, s, g);        \
-    else if (xq) hipLaunchKernelGGL((wgrad_rows_kernel<A, B, 2, false, true>), grid, dim3(256), ldsb, s, g);        \
-    else hipLaunchKernelGGL((wgrad_rows_kernel<A, B, 2, false, false>), grid, dim3(256), ldsb, s, g);               \
+    if (xp && xq) DVAE_LAUNCH((wgrad_rows_kernel<A, B, 2, true, true>), grid, dim3(256), ldsb, s, g);        \
+    else if (xp) DVAE_LAUNCH((wgrad_rows_kernel<A, B, 2, true, false>), grid, dim3(256), ldsb, s, g);        \
+    else if (xq) DVAE_LAUNCH((wgrad_rows_kernel<A, B, 2, false, true>), grid, dim3(256), ldsb, s, g);        \
+    else DVAE_LAUNCH((wgrad_rows_kernel<A, B, 2, false, false>), grid, dim3(256), ldsb, s, g);               \
   }
     if (C1 == 64) WGR_LAUNCH(64, 32) else WGR_LAUNCH(32, 16)
 #undef WGR_LAUNCH
@@ -2322,20 +2334,20 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
     const int ncb = (int)((C1 + 15) / 16);
     const dim3 grid((unsigned)p.split);
     if (g.p_y != nullptr) {
-      if (ncb <= 1) hipLaunchKernelGGL((conv_wgrad_c1_kernel<1, 8, true>), grid, dim3(256), 0, s, g);
-      else if (ncb <= 2) hipLaunchKernelGGL((conv_wgrad_c1_kernel<2, 4, true>), grid, dim3(256), 0, s, g);
-      else if (ncb <= 4) hipLaunchKernelGGL((conv_wgrad_c1_kernel<4, 2, true>), grid, dim3(256), 0, s, g);
-      else hipLaunchKernelGGL((conv_wgrad_c1_kernel<8, 1, true>), grid, dim3(256), 0, s, g);
-    } else if (ncb <= 1) hipLaunchKernelGGL((conv_wgrad_c1_kernel<1, 8, false>), grid, dim3(256), 0, s, g);
-    else if (ncb <= 2) hipLaunchKernelGGL((conv_wgrad_c1_kernel<2, 8, false>), grid, dim3(256), 0, s, g);
-    else if (ncb <= 4) hipLaunchKernelGGL((conv_wgrad_c1_kernel<4, 4, false>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((conv_wgrad_c1_kernel<8, 2, false>), grid, dim3(256), 0, s, g);
+      if (ncb <= 1) DVAE_LAUNCH((conv_wgrad_c1_kernel<1, 8, true>), grid, dim3(256), 0, s, g);
+      else if (ncb <= 2) DVAE_LAUNCH((conv_wgrad_c1_kernel<2, 4, true>), grid, dim3(256), 0, s, g);
+      else if (ncb <= 4) DVAE_LAUNCH((conv_wgrad_c1_kernel<4, 2, true>), grid, dim3(256), 0, s, g);
+      else DVAE_LAUNCH((conv_wgrad_c1_kernel<8, 1, true>), grid, dim3(256), 0, s, g);
+    } else if (ncb <= 1) DVAE_LAUNCH((conv_wgrad_c1_kernel<1, 8, false>), grid, dim3(256), 0, s, g);
+    else if (ncb <= 2) DVAE_LAUNCH((conv_wgrad_c1_kernel<2, 8, false>), grid, dim3(256), 0, s, g);
+    else if (ncb <= 4) DVAE_LAUNCH((conv_wgrad_c1_kernel<4, 4, false>), grid, dim3(256), 0, s, g);
+    else DVAE_LAUNCH((conv_wgrad_c1_kernel<8, 2, false>), grid, dim3(256), 0, s, g);
   } else {
     const dim3 grid((unsigned)p.tn, (unsigned)p.tm, (unsigned)p.split);
     const bool bf = dvae_mfma_precision() == DVAE_PRECISION_BF16;
 #define WG_LAUNCH(TILE)                                                                     \
-  if (bf) hipLaunchKernelGGL((conv_wgrad_kernel<TILE, true>), grid, dim3(256), 0, s, g);     \
-  else hipLaunchKernelGGL((conv_wgrad_kernel<TILE, false>), grid, dim3(256), 0, s, g);
+  if (bf) DVAE_LAUNCH((conv_wgrad_kernel<TILE, true>), grid, dim3(256), 0, s, g);     \
+  else DVAE_LAUNCH((conv_wgrad_kernel<TILE, false>), grid, dim3(256), 0, s, g);
     typedef Tile<32, 128, 1, 4, false, false> W32;
     typedef Tile<64, 128, 2, 2, false, false> W64;
     typedef Tile<128, 128, 2, 2, false, false> W128;
@@ -2355,12 +2367,12 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
   if (runs > 1) {
     float* part = ws + (int64_t)p.split * C1 * C2 * 16;
     const int zchunk = (p.split + runs - 1) / runs, nruns = (p.split + zchunk - 1) / zchunk;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nb, (unsigned)nruns), dim3(256), 0, s, (const float*)ws,
+    DVAE_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)nb, (unsigned)nruns), dim3(256), 0, s, (const float*)ws,
                        p.split, zchunk, part, dw, C1, C2);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nb, 1), dim3(256), 0, s, (const float*)part, nruns, nruns,
+    DVAE_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)nb, 1), dim3(256), 0, s, (const float*)part, nruns, nruns,
                        part, dw, C1, C2);
   } else {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nb, 1), dim3(256), 0, s, (const float*)ws, p.split, p.split,
+    DVAE_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)nb, 1), dim3(256), 0, s, (const float*)ws, p.split, p.split,
                        ws, dw, C1, C2);
   }
   DVAE_LAUNCH_CHECK("conv4s2_wgrad_reduce");
@@ -2597,12 +2609,13 @@ extern "C" int dvae_deconv4s2_final_fwd_f32(const float* x, const float* in_scal
   g.bands = (int)(H / g.R);
   const size_t lds = (size_t)(g.R + 2) * W * 16 * 4;
   const bool vec_affine = in_scale == nullptr || (aligned16(in_scale) && aligned16(in_shift));
+  DVAE_WORK(4.0 * ((double)N * H * W * Cin + (double)N * 4 * H * W), DVAE_UNIT_BYTE);      // read x, write y
   if (Cin == 32 && vec_affine)
-    hipLaunchKernelGGL((deconv_final_fixed_kernel<2, 4>), dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);
+    DVAE_LAUNCH((deconv_final_fixed_kernel<2, 4>), dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);
   else if (Cin == 64 && vec_affine)
-    hipLaunchKernelGGL((deconv_final_fixed_kernel<4, 2>), dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);
+    DVAE_LAUNCH((deconv_final_fixed_kernel<4, 2>), dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);
   else
-    hipLaunchKernelGGL(deconv_final_kernel, dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);
+    DVAE_LAUNCH(deconv_final_kernel, dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);
   DVAE_LAUNCH_CHECK("deconv4s2_final_fwd");
   return 0;
 }

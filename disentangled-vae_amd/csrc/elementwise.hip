@@ -61,7 +61,8 @@ extern "C" int dvae_split_mean_diff_f32(const float* video, float* mean, float* 
   DVAE_REQUIRE(B > 0 && T >= 1 && P > 0 && P % 4 == 0, "split_mean_diff: need B>0, T>=1, P%%4==0 (B=%ld T=%ld P=%ld)",
                (long)B, (long)T, (long)P);
   const int64_t total = B * (P / 4);
-  hipLaunchKernelGGL(split_mean_diff_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, ST(stream),
+  DVAE_WORK(4.0 * ((double)B * T * P + (double)B * P + (double)B * (T - 1) * P), DVAE_UNIT_BYTE);
+  DVAE_LAUNCH(split_mean_diff_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, ST(stream),
                      (const float4*)video, (float4*)mean, (float4*)diff, total, (int)T, P / 4);
   DVAE_LAUNCH_CHECK("split_mean_diff");
   return 0;
@@ -107,7 +108,7 @@ extern "C" int dvae_render_clips_f32(const float* bank, int64_t bank_size, const
                (long)frame_size, (long)digit_size);
   DVAE_REQUIRE((((uintptr_t)video) & 15) == 0, "render_clips: video must be 16-byte aligned");
   const int64_t total4 = B * T * frame_size * (frame_size / 4);
-  hipLaunchKernelGGL(render_clips_kernel, dim3((unsigned)ceil_div64(total4, 256)), dim3(256), 0, ST(stream), bank,
+  DVAE_LAUNCH(render_clips_kernel, dim3((unsigned)ceil_div64(total4, 256)), dim3(256), 0, ST(stream), bank,
                      (const int*)digit_idx, (const int*)positions, (float4*)video, total4, (int)T, (int)num_digits,
                      (int)frame_size, (int)digit_size);
   DVAE_LAUNCH_CHECK("render_clips");
@@ -200,10 +201,11 @@ extern "C" int dvae_recon_loss_fwd_f32(const float* recon, const float* target, 
   DVAE_REQUIRE(kind == 0 || kind == 1, "recon_loss_fwd: kind must be 0 (mse) or 1 (bce)");
   DVAE_REQUIRE(((uintptr_t)ws & 7) == 0, "recon_loss_fwd: workspace must be 8-byte aligned");
   const int nb = recon_blocks(B, P);
-  hipLaunchKernelGGL(recon_loss_fwd_kernel, dim3(nb), dim3(256), 0, ST(stream), (const float4*)recon,
+  DVAE_WORK(8.0 * (double)B * T * P, DVAE_UNIT_BYTE);                      // recon and target, once each
+  DVAE_LAUNCH(recon_loss_fwd_kernel, dim3(nb), dim3(256), 0, ST(stream), (const float4*)recon,
                      (const float4*)target, (double*)ws, B * (P / 4), (int)T, P / 4, kind, with_temporal);
   DVAE_LAUNCH_CHECK("recon_loss_fwd");
-  hipLaunchKernelGGL(recon_loss_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, nb, out,
+  DVAE_LAUNCH(recon_loss_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, nb, out,
                      (double)B, (double)T, (double)P);
   DVAE_LAUNCH_CHECK("recon_loss_finalize");
   return 0;
@@ -273,10 +275,10 @@ extern "C" int dvae_recon_metrics_f32(const float* recon, const float* target, f
   DVAE_REQUIRE(((((uintptr_t)recon) | ((uintptr_t)target)) & 15) == 0, "recon_metrics: clips must be 16-byte aligned");
   DVAE_REQUIRE(ws != nullptr && ((uintptr_t)ws & 7) == 0, "recon_metrics: workspace must be 8-byte aligned");
   const int nb = recon_blocks(B, P);
-  hipLaunchKernelGGL(recon_metrics_kernel, dim3(nb), dim3(256), 0, ST(stream), (const float4*)recon,
+  DVAE_LAUNCH(recon_metrics_kernel, dim3(nb), dim3(256), 0, ST(stream), (const float4*)recon,
                      (const float4*)target, (double*)ws, B * (P / 4), (int)T, P / 4);
   DVAE_LAUNCH_CHECK("recon_metrics");
-  hipLaunchKernelGGL(recon_metrics_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, nb, out,
+  DVAE_LAUNCH(recon_metrics_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, nb, out,
                      (double)B, (double)T, (double)P, (double)max_val);
   DVAE_LAUNCH_CHECK("recon_metrics_finalize");
   return 0;
@@ -330,10 +332,10 @@ extern "C" int dvae_recon_metrics_noalloc_f32(const float* recon, const float* t
   if (ws == nullptr) return -EIO;
   // every partial the finalize kernel reads is written by this launch first: nothing to clear
   const int nb = recon_blocks(B, P);
-  hipLaunchKernelGGL(recon_metrics_kernel, dim3(nb), dim3(256), 0, ST(stream), (const float4*)recon,
+  DVAE_LAUNCH(recon_metrics_kernel, dim3(nb), dim3(256), 0, ST(stream), (const float4*)recon,
                      (const float4*)target, ws, B * (P / 4), (int)T, P / 4);
   DVAE_LAUNCH_CHECK("recon_metrics_noalloc");
-  hipLaunchKernelGGL(recon_metrics_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, nb, out,
+  DVAE_LAUNCH(recon_metrics_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, nb, out,
                      (double)B, (double)T, (double)P, (double)max_val);
   DVAE_LAUNCH_CHECK("recon_metrics_noalloc_finalize");
   return 0;
@@ -390,7 +392,8 @@ extern "C" int dvae_recon_loss_bwd_f32(const float* recon, const float* target, 
   // out[1] = sum(l)/B ; out[2] = sum(d^2)/B
   const float w_rec = 1.f / (float)B;
   const float w_tmp = (T > 1) ? 2.f * temporal_weight / (float)B : 0.f;
-  hipLaunchKernelGGL(recon_loss_bwd_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, ST(stream),
+  DVAE_WORK(12.0 * (double)B * T * P, DVAE_UNIT_BYTE);                     // recon, target in; gradient out
+  DVAE_LAUNCH(recon_loss_bwd_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, ST(stream),
                      (const float4*)recon, (const float4*)target, gscale, (float4*)drecon, total, (int)T, P / 4,
                      kind, w_rec, w_tmp);
   DVAE_LAUNCH_CHECK("recon_loss_bwd");
@@ -418,7 +421,7 @@ __global__ void reparam_bwd_kernel(const float* dz, const float* logvar, const f
 extern "C" int dvae_reparam_fwd_f32(const float* mu, const float* logvar, const float* eps, float* z, int64_t n,
                                     dvae_stream_t stream) {
   DVAE_REQUIRE(n > 0, "reparam_fwd: empty");
-  hipLaunchKernelGGL(reparam_fwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ST(stream), mu, logvar,
+  DVAE_LAUNCH(reparam_fwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ST(stream), mu, logvar,
                      eps, z, n);
   DVAE_LAUNCH_CHECK("reparam_fwd");
   return 0;
@@ -427,7 +430,7 @@ extern "C" int dvae_reparam_fwd_f32(const float* mu, const float* logvar, const 
 extern "C" int dvae_reparam_bwd_f32(const float* dz, const float* logvar, const float* eps, float* dmu,
                                     float* dlogvar, int64_t n, dvae_stream_t stream) {
   DVAE_REQUIRE(n > 0, "reparam_bwd: empty");
-  hipLaunchKernelGGL(reparam_bwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ST(stream), dz, logvar,
+  DVAE_LAUNCH(reparam_bwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ST(stream), dz, logvar,
                      eps, dmu, dlogvar, n);
   DVAE_LAUNCH_CHECK("reparam_bwd");
   return 0;
@@ -494,7 +497,7 @@ __global__ void kl_bwd_kernel(const float* mu, const float* logvar, const float*
 extern "C" int dvae_kl_fwd_f32(const float* mu, const float* logvar, float* out, int64_t B, int64_t D,
                                float free_bits, dvae_stream_t stream) {
   DVAE_REQUIRE(B > 0 && D > 0, "kl_fwd: empty");
-  hipLaunchKernelGGL(kl_fwd_kernel, dim3(1), dim3(1024), 0, ST(stream), mu, logvar, out, B, D, free_bits);
+  DVAE_LAUNCH(kl_fwd_kernel, dim3(1), dim3(1024), 0, ST(stream), mu, logvar, out, B, D, free_bits);
   DVAE_LAUNCH_CHECK("kl_fwd");
   return 0;
 }
@@ -503,7 +506,7 @@ extern "C" int dvae_kl_bwd_f32(const float* mu, const float* logvar, const float
                                float* dlogvar, int64_t B, int64_t D, float free_bits, dvae_stream_t stream) {
   DVAE_REQUIRE(B > 0 && D > 0, "kl_bwd: empty");
   const int64_t n = B * D;
-  hipLaunchKernelGGL(kl_bwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ST(stream), mu, logvar,
+  DVAE_LAUNCH(kl_bwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ST(stream), mu, logvar,
                      gscale, coef / (float)B, dmu, dlogvar, n, free_bits);
   DVAE_LAUNCH_CHECK("kl_bwd");
   return 0;
@@ -623,10 +626,10 @@ extern "C" int dvae_indep_fwd_f32(const float* zc, const float* zm, float* out, 
   float* mean_m = inv_c + Dc;
   float* inv_m = mean_m + Dm;
   float* part = inv_m + Dm;
-  hipLaunchKernelGGL(indep_stats_kernel, dim3((unsigned)Dc), dim3(256), 0, ST(stream), zc, mean_c, inv_c, B, Dc);
-  hipLaunchKernelGGL(indep_stats_kernel, dim3((unsigned)Dm), dim3(256), 0, ST(stream), zm, mean_m, inv_m, B, Dm);
-  hipLaunchKernelGGL(indep_corr_kernel, dim3((unsigned)Dc), dim3(256), 0, ST(stream), zc, zm, ws, B, Dc, Dm);
-  hipLaunchKernelGGL(indep_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), part, out, Dc, Dm);
+  DVAE_LAUNCH(indep_stats_kernel, dim3((unsigned)Dc), dim3(256), 0, ST(stream), zc, mean_c, inv_c, B, Dc);
+  DVAE_LAUNCH(indep_stats_kernel, dim3((unsigned)Dm), dim3(256), 0, ST(stream), zm, mean_m, inv_m, B, Dm);
+  DVAE_LAUNCH(indep_corr_kernel, dim3((unsigned)Dc), dim3(256), 0, ST(stream), zc, zm, ws, B, Dc, Dm);
+  DVAE_LAUNCH(indep_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), part, out, Dc, Dm);
   DVAE_LAUNCH_CHECK("indep_fwd");
   return 0;
 }
@@ -640,9 +643,9 @@ extern "C" int dvae_indep_bwd_f32(const float* zc, const float* zm, const float*
   const float* inv_c = mean_c + Dc;
   const float* mean_m = inv_c + Dc;
   const float* inv_m = mean_m + Dm;
-  hipLaunchKernelGGL(indep_bwd_kernel, dim3((unsigned)Dc), dim3(256), (size_t)B * 4, ST(stream), zc, zm, corr, Dm,
+  DVAE_LAUNCH(indep_bwd_kernel, dim3((unsigned)Dc), dim3(256), (size_t)B * 4, ST(stream), zc, zm, corr, Dm,
                      (int64_t)1, mean_c, inv_c, mean_m, inv_m, gscale, coef, dzc, B, Dc, Dm);
-  hipLaunchKernelGGL(indep_bwd_kernel, dim3((unsigned)Dm), dim3(256), (size_t)B * 4, ST(stream), zm, zc, corr,
+  DVAE_LAUNCH(indep_bwd_kernel, dim3((unsigned)Dm), dim3(256), (size_t)B * 4, ST(stream), zm, zc, corr,
                      (int64_t)1, Dm, mean_m, inv_m, mean_c, inv_c, gscale, coef, dzm, B, Dm, Dc);
   DVAE_LAUNCH_CHECK("indep_bwd");
   return 0;
@@ -690,7 +693,7 @@ extern "C" int dvae_bn_finalize_f32(const float* partials, int64_t nparts, int64
                                     float* shift, float* mean, float* invstd, dvae_stream_t stream) {
   DVAE_REQUIRE(nparts > 0 && M > 0 && C > 0, "bn_finalize: empty");
   DVAE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running buffers come in pairs");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), partials, nparts, (double)M, C,
+  DVAE_LAUNCH(bn_finalize_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), partials, nparts, (double)M, C,
                      gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean,
                      invstd);
   DVAE_LAUNCH_CHECK("bn_finalize");
@@ -711,7 +714,7 @@ extern "C" int dvae_bn_eval_affine_f32(const float* gamma, const float* beta, co
                                        const float* running_var, float eps, float* scale, float* shift, int64_t C,
                                        dvae_stream_t stream) {
   DVAE_REQUIRE(C > 0, "bn_eval_affine: empty");
-  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((unsigned)ceil_div64(C, 256)), dim3(256), 0, ST(stream), gamma, beta,
+  DVAE_LAUNCH(bn_eval_affine_kernel, dim3((unsigned)ceil_div64(C, 256)), dim3(256), 0, ST(stream), gamma, beta,
                      running_mean, running_var, eps, scale, shift, C);
   DVAE_LAUNCH_CHECK("bn_eval_affine");
   return 0;
@@ -732,7 +735,8 @@ extern "C" int dvae_affine_act_f32(const float* x, const float* scale, const flo
   const int64_t total4 = M * C / 4;
   int64_t nb = ceil_div64(total4, 256);
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(affine_act_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), (const float4*)x, scale, shift,
+  DVAE_WORK(8.0 * (double)M * C, DVAE_UNIT_BYTE);
+  DVAE_LAUNCH(affine_act_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), (const float4*)x, scale, shift,
                      act, (float4*)out, total4, (int)(C / 4));
   DVAE_LAUNCH_CHECK("affine_act");
   return 0;
@@ -885,7 +889,7 @@ extern "C" int dvae_bn_bwd_coeffs_f32(const float* partials, int64_t nparts, con
                                       int64_t M, int64_t C, dvae_stream_t stream) {
   DVAE_REQUIRE(M > 0 && C > 0 && nparts > 0, "bn_bwd_coeffs: empty");
   DVAE_REQUIRE(partials && scale && mean && invstd && dgamma && dbeta && coef_a && coef_b, "bn_bwd_coeffs: null argument");
-  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), partials, nparts, C, scale, mean,
+  DVAE_LAUNCH(bn_bwd_coeffs_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), partials, nparts, C, scale, mean,
                      invstd, 1.f / (float)M, dgamma, dbeta, coef_a, coef_b);
   DVAE_LAUNCH_CHECK("bn_bwd_coeffs");
   return 0;
@@ -947,14 +951,16 @@ extern "C" int dvae_bn_bwd_f32(float* du, const float* y, const float* scale, co
   (void)gamma;  // scale already equals gamma*invstd
   DVAE_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd: need C%%4==0 (C=%ld)", (long)C);
   const ColsumGeom g = colsum_geom(M, C);
-  hipLaunchKernelGGL(colsum_kernel<0>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), du, y, scale, shift, mean,
+  DVAE_WORK(8.0 * (double)M * C, DVAE_UNIT_BYTE);                          // du and y, once each
+  DVAE_LAUNCH(colsum_kernel<0>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), du, y, scale, shift, mean,
                      invstd, 0, ws, M, C, g.tx, g.ty);
   DVAE_LAUNCH_CHECK("bn_bwd_reduce");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), (const float*)ws, g.gx, 2, C,
+  DVAE_LAUNCH(colsum_finalize_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), (const float*)ws, g.gx, 2, C,
                      dbeta, dgamma);
   DVAE_LAUNCH_CHECK("bn_bwd_finalize");
   const int64_t total4 = M * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_blocks(total4, C / 4)), dim3(256), 0, ST(stream), (float4*)du, (const float4*)y,
+  DVAE_WORK(12.0 * (double)M * C, DVAE_UNIT_BYTE);                         // du, y in; dy out
+  DVAE_LAUNCH(bn_bwd_apply_kernel, dim3(bn_apply_blocks(total4, C / 4)), dim3(256), 0, ST(stream), (float4*)du, (const float4*)y,
                      scale, shift, mean, invstd, (const float*)dbeta, (const float*)dgamma, 1.f / (float)M, total4,
                      (int)(C / 4));
   DVAE_LAUNCH_CHECK("bn_bwd_apply");
@@ -969,7 +975,8 @@ extern "C" int dvae_bn_bwd_reduce_f32(const float* du, const float* y, const flo
                                       dvae_stream_t stream) {
   DVAE_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd_reduce: need C%%4==0 (C=%ld)", (long)C);
   const ColsumGeom g = colsum_geom(M, C);
-  hipLaunchKernelGGL(colsum_kernel<0>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), const_cast<float*>(du), y,
+  DVAE_WORK(8.0 * (double)M * C, DVAE_UNIT_BYTE);                          // du and y, once each
+  DVAE_LAUNCH(colsum_kernel<0>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), const_cast<float*>(du), y,
                      scale, shift, mean, invstd, 0, partials, M, C, g.tx, g.ty);
   DVAE_LAUNCH_CHECK("bn_bwd_reduce");
   return 0;
@@ -981,11 +988,12 @@ extern "C" int dvae_bn_bwd_from_partials_f32(float* du, const float* y, const fl
                                              dvae_stream_t stream) {
   DVAE_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && nparts > 0, "bn_bwd_from_partials: need C%%4==0 and partial rows (C=%ld)",
                (long)C);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), partials, nparts, 2, C, dbeta,
+  DVAE_LAUNCH(colsum_finalize_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), partials, nparts, 2, C, dbeta,
                      dgamma);
   DVAE_LAUNCH_CHECK("bn_bwd_finalize");
   const int64_t total4 = M * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_blocks(total4, C / 4)), dim3(256), 0, ST(stream), (float4*)du, (const float4*)y,
+  DVAE_WORK(12.0 * (double)M * C, DVAE_UNIT_BYTE);                         // du, y in; dy out
+  DVAE_LAUNCH(bn_bwd_apply_kernel, dim3(bn_apply_blocks(total4, C / 4)), dim3(256), 0, ST(stream), (float4*)du, (const float4*)y,
                      scale, shift, mean, invstd, (const float*)dbeta, (const float*)dgamma, 1.f / (float)M, total4,
                      (int)(C / 4));
   DVAE_LAUNCH_CHECK("bn_bwd_apply");
@@ -998,12 +1006,13 @@ extern "C" int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, flo
   DVAE_REQUIRE(act == DVAE_ACT_NONE || act == DVAE_ACT_LRELU, "bias_act_bwd: unsupported activation %d", act);
   if (act == DVAE_ACT_NONE && dbias == nullptr) return 0;
   const ColsumGeom g = colsum_geom(M, N);
-  hipLaunchKernelGGL(colsum_kernel<1>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), dout, out,
+  DVAE_WORK((act == DVAE_ACT_LRELU ? 12.0 : 4.0) * (double)M * N, DVAE_UNIT_BYTE);
+  DVAE_LAUNCH(colsum_kernel<1>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), dout, out,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, ws,
                      M, N, g.tx, g.ty);
   DVAE_LAUNCH_CHECK("bias_act_bwd");
   if (dbias) {
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)N), dim3(256), 0, ST(stream), (const float*)ws, g.gx, 1,
+    DVAE_LAUNCH(colsum_finalize_kernel, dim3((unsigned)N), dim3(256), 0, ST(stream), (const float*)ws, g.gx, 1,
                        N, dbias, (float*)nullptr);
     DVAE_LAUNCH_CHECK("bias_act_bwd_finalize");
   }
@@ -1040,11 +1049,12 @@ extern "C" int dvae_sigmoid_bwd_f32(const float* drecon, const float* recon, flo
   DVAE_REQUIRE(((uintptr_t)ws & 7) == 0, "sigmoid_bwd: workspace must be 8-byte aligned");
   int64_t nb = ceil_div64(n, 256 * 8);
   if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), drecon, recon, dlogit,
+  DVAE_WORK(12.0 * (double)n, DVAE_UNIT_BYTE);
+  DVAE_LAUNCH(sigmoid_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), drecon, recon, dlogit,
                      (double*)ws, n);
   DVAE_LAUNCH_CHECK("sigmoid_bwd");
   if (dbias) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, (int)nb, dbias);
+    DVAE_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, (int)nb, dbias);
     DVAE_LAUNCH_CHECK("sigmoid_bwd_sum");
   }
   return 0;
@@ -1110,7 +1120,7 @@ extern "C" int dvae_permute3_f32(const float* in, float* out, int64_t D0, int64_
   if (p0 == 0 && p1 == 2 && p2 == 1 && D1 > 1 && D2 > 1 && D1 < (1 << 30) && D2 < (1 << 30)) {
     const int64_t t1 = ceil_div64(D1, 32), t2 = ceil_div64(D2, 32);
     if (D0 * t1 * t2 < (1LL << 31) && t1 * t2 < (1LL << 31)) {
-      hipLaunchKernelGGL(transpose_inner_kernel, dim3((unsigned)(D0 * t1 * t2)), dim3(256), 0, ST(stream), in, out,
+      DVAE_LAUNCH(transpose_inner_kernel, dim3((unsigned)(D0 * t1 * t2)), dim3(256), 0, ST(stream), in, out,
                          (int)D1, (int)D2, (int)t1, (int)t2);
       DVAE_LAUNCH_CHECK("permute3");
       return 0;
@@ -1121,14 +1131,14 @@ extern "C" int dvae_permute3_f32(const float* in, float* out, int64_t D0, int64_
     const int64_t total = D0 * D1 * (D2 / 4);
     int64_t nbv = ceil_div64(total, 256);
     if (nbv > 8192) nbv = 8192;
-    hipLaunchKernelGGL(swap_outer_kernel, dim3((unsigned)nbv), dim3(256), 0, ST(stream), (const float4*)in, (float4*)out,
+    DVAE_LAUNCH(swap_outer_kernel, dim3((unsigned)nbv), dim3(256), 0, ST(stream), (const float4*)in, (float4*)out,
                        (int)D0, (int)D1, (int)(D2 / 4), total);
     DVAE_LAUNCH_CHECK("permute3");
     return 0;
   }
   int64_t nb = ceil_div64(D0 * D1 * D2, 256);
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(permute3_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), in, out, D0, D1, D2, p0, p1, p2);
+  DVAE_LAUNCH(permute3_kernel, dim3((unsigned)nb), dim3(256), 0, ST(stream), in, out, D0, D1, D2, p0, p1, p2);
   DVAE_LAUNCH_CHECK("permute3");
   return 0;
 }
@@ -1156,7 +1166,7 @@ extern "C" int dvae_weighted_sum_f32(int n, const float* const* terms, const flo
     a.src[i] = terms[i];
     a.coef[i] = coefs[i];
   }
-  hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(64), 0, ST(stream), a, out);
+  DVAE_LAUNCH(weighted_sum_kernel, dim3(1), dim3(64), 0, ST(stream), a, out);
   DVAE_LAUNCH_CHECK("weighted_sum");
   return 0;
 }

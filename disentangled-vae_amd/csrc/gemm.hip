@@ -248,10 +248,11 @@ template <int KIND>
 static int launch_gemm(const char* name, GemmArgs g, float* ws, hipStream_t stream) {
   if (small_gemm_shape(g.M, g.N, g.K)) {
     const dim3 grid((unsigned)ceil_div64(g.N, 16), (unsigned)ceil_div64(g.M, 16));
+    DVAE_WORK(2.0 * (double)g.M * g.N * g.K, DVAE_UNIT_FLOP);
     if (dvae_mfma_precision() == DVAE_PRECISION_BF16)
-      hipLaunchKernelGGL((small_gemm_kernel<KIND, true>), grid, dim3(64 * SG_WAVES), 0, stream, g);
+      DVAE_LAUNCH((small_gemm_kernel<KIND, true>), grid, dim3(64 * SG_WAVES), 0, stream, g);
     else
-      hipLaunchKernelGGL((small_gemm_kernel<KIND, false>), grid, dim3(64 * SG_WAVES), 0, stream, g);
+      DVAE_LAUNCH((small_gemm_kernel<KIND, false>), grid, dim3(64 * SG_WAVES), 0, stream, g);
     DVAE_LAUNCH_CHECK(name);
     return 0;
   }
@@ -267,14 +268,16 @@ static int launch_gemm(const char* name, GemmArgs g, float* ws, hipStream_t stre
   const int prec = dvae_mfma_precision();
   typedef Tile<32, 128, 1, 4, AKC, BKC> Skinny;
   typedef Tile<128, 128, 2, 2, AKC, BKC> Big;
+  int64_t rows = g.M;                  // rows of C the next launch computes
 #define GEMM_LAUNCH(TILE, KIND_, GRID)                                                                   \
   {                                                                                                      \
+    DVAE_WORK(2.0 * (double)rows * g.N * g.K, DVAE_UNIT_FLOP);                                           \
     if (prec == DVAE_PRECISION_BF16)                                                                     \
-      hipLaunchKernelGGL((gemm_kernel<TILE, KIND_, PREC_BF16>), GRID, dim3(256), 0, stream, g);          \
+      DVAE_LAUNCH((gemm_kernel<TILE, KIND_, PREC_BF16>), GRID, dim3(256), 0, stream, g);          \
     else if (prec == DVAE_PRECISION_F32_SPLIT)                                                           \
-      hipLaunchKernelGGL((gemm_kernel<TILE, KIND_, PREC_SPLIT>), GRID, dim3(256), 0, stream, g);         \
+      DVAE_LAUNCH((gemm_kernel<TILE, KIND_, PREC_SPLIT>), GRID, dim3(256), 0, stream, g);         \
     else                                                                                                 \
-      hipLaunchKernelGGL((gemm_kernel<TILE, KIND_, PREC_F32>), GRID, dim3(256), 0, stream, g);           \
+      DVAE_LAUNCH((gemm_kernel<TILE, KIND_, PREC_F32>), GRID, dim3(256), 0, stream, g);           \
   }
   g.tm0 = 0;
   // tiles that fill the 512 workgroup slots a whole number of times and then leave between a fifth and
@@ -288,8 +291,10 @@ static int launch_gemm(const char* name, GemmArgs g, float* ws, hipStream_t stre
       typedef Tile<128, 64, 4, 1, true, true> Narrow;
       const dim3 head((unsigned)p.tn, (unsigned)head_tm, 1);
       const dim3 tail((unsigned)ceil_div64(g.N, 64), (unsigned)(p.tm - head_tm), 1);
+      rows = head_tm * 128;
       GEMM_LAUNCH(Wide, G_NT, head)
       g.tm0 = (int)head_tm;
+      rows = g.M - head_tm * 128;
       GEMM_LAUNCH(Narrow, G_NT, tail)
       DVAE_LAUNCH_CHECK(name);
       return 0;
@@ -306,10 +311,10 @@ static int launch_gemm(const char* name, GemmArgs g, float* ws, hipStream_t stre
     int64_t nb = ceil_div64(g.M * g.N / (v4 ? 4 : 1), 256);
     if (nb > 2048) nb = 2048;
     if (v4)
-      hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)ws, p.split,
+      DVAE_LAUNCH(splitk_reduce_kernel<4>, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)ws, p.split,
                          g.bias, g.act, g.accumulate, g.C, g.ldc, g.M, g.N);
     else
-      hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)ws, p.split,
+      DVAE_LAUNCH(splitk_reduce_kernel<1>, dim3((unsigned)nb), dim3(256), 0, stream, (const float*)ws, p.split,
                          g.bias, g.act, g.accumulate, g.C, g.ldc, g.M, g.N);
     DVAE_LAUNCH_CHECK(name);
   }

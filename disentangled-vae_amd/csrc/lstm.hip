@@ -159,7 +159,8 @@ extern "C" int dvae_lstm_step_fwd_f32(const float* xproj, int64_t ld_xproj, cons
   LstmFwdArgs g{xproj, ld_xproj, x, ld_x, w_ih, I, h_prev, ld_h, c_prev, ld_c, w_hh, b_ih, b_hh,
                 gates_out, h_out, ld_hout, c_out, ld_cout, B, H};
   const dim3 grid((unsigned)(H / 8), (unsigned)ceil_div64(B, 32));
-  hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(64 * FWD_WAVES), 0, ST(stream), g);
+  DVAE_WORK(2.0 * (double)B * 4 * H * ((x ? I : 0) + (h_prev ? H : 0)), DVAE_UNIT_FLOP);
+  DVAE_LAUNCH(lstm_step_fwd_kernel, grid, dim3(64 * FWD_WAVES), 0, ST(stream), g);
   DVAE_LAUNCH_CHECK("lstm_step_fwd");
   return 0;
 }
@@ -195,7 +196,7 @@ extern "C" int dvae_lstm_step_bwd_pointwise_f32(const float* dh, int64_t ld_dh, 
                                                 int64_t ld_dcprev, int64_t B, int64_t H, dvae_stream_t stream) {
   DVAE_REQUIRE(B > 0 && H > 0, "lstm_step_bwd_pointwise: empty");
   DVAE_REQUIRE(dh && gates && c && dgates && dc_prev, "lstm_step_bwd_pointwise: null argument");
-  hipLaunchKernelGGL(lstm_bwd_pointwise_kernel, dim3((unsigned)ceil_div64(B * H, 256)), dim3(256), 0, ST(stream), dh,
+  DVAE_LAUNCH(lstm_bwd_pointwise_kernel, dim3((unsigned)ceil_div64(B * H, 256)), dim3(256), 0, ST(stream), dh,
                      ld_dh, dc, ld_dc, gates, c_prev, ld_cprev, c, ld_c, dgates, dc_prev, ld_dcprev, B, H);
   DVAE_LAUNCH_CHECK("lstm_step_bwd_pointwise");
   return 0;
@@ -339,7 +340,8 @@ extern "C" int dvae_lstm_bwd_step_f32(const float* dg_t, int64_t ld_dg, const fl
   LstmBwdStepArgs a{SkinnyArgs{dg_t, ld_dg, wt, ld_wt, dh_prev, ld_dh, B, H, K, 1},
                     gates, c_prev, ld_cprev, c, ld_c, dc, ld_dc, dgates, dc_prev, ld_dcprev};
   const dim3 grid((unsigned)ceil_div64(H, 16), (unsigned)ceil_div64(B, 16));
-  hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(64 * SK_WAVES), 0, ST(stream), a);
+  DVAE_WORK(2.0 * (double)B * H * K, DVAE_UNIT_FLOP);
+  DVAE_LAUNCH(lstm_bwd_step_kernel, grid, dim3(64 * SK_WAVES), 0, ST(stream), a);
   DVAE_LAUNCH_CHECK("lstm_bwd_step");
   return 0;
 }
@@ -353,7 +355,8 @@ extern "C" int dvae_skinny_gemm_nt_f32(const float* a, int64_t ld_a, const float
   DVAE_REQUIRE(aligned16(a) && aligned16(wt), "skinny_gemm_nt: 16-byte alignment");
   SkinnyArgs g{a, ld_a, wt, ld_wt, out, ld_out, B, N, K, accumulate};
   const dim3 grid((unsigned)ceil_div64(N, 16), (unsigned)ceil_div64(B, 16));
-  hipLaunchKernelGGL(skinny_gemm_nt_kernel, grid, dim3(64 * SK_WAVES), 0, ST(stream), g);
+  DVAE_WORK(2.0 * (double)B * N * K, DVAE_UNIT_FLOP);
+  DVAE_LAUNCH(skinny_gemm_nt_kernel, grid, dim3(64 * SK_WAVES), 0, ST(stream), g);
   DVAE_LAUNCH_CHECK("skinny_gemm_nt");
   return 0;
 }

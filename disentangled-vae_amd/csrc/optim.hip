@@ -167,11 +167,12 @@ extern "C" int dvae_grad_norm_f32(int64_t n, const float* const* grads, const in
     MTTable t;
     const int blocks = fill_table(t, first, n, numel);
     for (int i = 0; i < t.n; ++i) t.g[i] = (void*)grads[first + i];
-    hipLaunchKernelGGL(mt_sumsq_kernel, dim3(blocks), dim3(256), 0, ST(stream), t, (double*)ws, part);
+    { double el = 0; for (int i = 0; i < t.n; ++i) el += (double)t.numel[i]; DVAE_WORK(4.0 * el, DVAE_UNIT_BYTE); }
+    DVAE_LAUNCH(mt_sumsq_kernel, dim3(blocks), dim3(256), 0, ST(stream), t, (double*)ws, part);
     DVAE_LAUNCH_CHECK("grad_norm");
     part += blocks;
   }
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, part, max_norm,
+  DVAE_LAUNCH(norm_finalize_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, part, max_norm,
                      norm_out);
   DVAE_LAUNCH_CHECK("grad_norm_finalize");
   return 0;
@@ -184,7 +185,7 @@ extern "C" int dvae_scale_tensors_f32(int64_t n, float* const* tensors, const in
     MTTable t;
     const int blocks = fill_table(t, first, n, numel);
     for (int i = 0; i < t.n; ++i) t.g[i] = (void*)tensors[first + i];
-    hipLaunchKernelGGL(mt_scale_kernel, dim3(blocks), dim3(256), 0, ST(stream), t, coef);
+    DVAE_LAUNCH(mt_scale_kernel, dim3(blocks), dim3(256), 0, ST(stream), t, coef);
     DVAE_LAUNCH_CHECK("scale_tensors");
   }
   return 0;
@@ -205,7 +206,7 @@ __global__ void adam_advance_kernel(float* dyn, double beta1, double beta2) {
 extern "C" int dvae_adam_advance_f32(float* dyn, double beta1, double beta2, dvae_stream_t stream) {
   DVAE_REQUIRE(dyn != nullptr, "adam_advance: null state");
   DVAE_REQUIRE(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0, "adam_advance: betas must be in [0, 1)");
-  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, ST(stream), dyn, beta1, beta2);
+  DVAE_LAUNCH(adam_advance_kernel, dim3(1), dim3(64), 0, ST(stream), dyn, beta1, beta2);
   DVAE_LAUNCH_CHECK("adam_advance");
   return 0;
 }
@@ -227,7 +228,8 @@ extern "C" int dvae_adam_step_f32(int64_t n, float* const* params, const float* 
       t.m[i] = (void*)exp_avg[first + i];
       t.v[i] = (void*)exp_avg_sq[first + i];
     }
-    hipLaunchKernelGGL(mt_adam_kernel, dim3(blocks), dim3(256), 0, ST(stream), t, lr, beta1, beta2, eps, weight_decay,
+    { double el = 0; for (int i = 0; i < t.n; ++i) el += (double)t.numel[i]; DVAE_WORK(28.0 * el, DVAE_UNIT_BYTE); }
+    DVAE_LAUNCH(mt_adam_kernel, dim3(blocks), dim3(256), 0, ST(stream), t, lr, beta1, beta2, eps, weight_decay,
                        bias_correction1, bc2_sqrt, grad_coef, dyn);
     DVAE_LAUNCH_CHECK("adam_step");
   }

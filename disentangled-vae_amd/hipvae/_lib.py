@@ -91,6 +91,9 @@ SIGNATURES = {
     'dvae_scale_tensors_f32': (I, [L, POINTER(c_void_p), POINTER(c_int64), P, P]),
     'dvae_adam_step_f32': (I, [L, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                POINTER(c_int64), F, F, F, F, F, F, F, P, P, P]),
+    'dvae_trace_begin': (I, [L]),
+    'dvae_trace_end': (L, []),
+    'dvae_trace_read': (I, [L, ctypes.c_char_p, L, POINTER(c_float), POINTER(c_double), POINTER(c_int)]),
     'dvae_adam_advance_f32': (I, [P, c_double, c_double, P]),
 }
 

@@ -667,3 +667,23 @@ def adam_advance(dyn: Tensor, beta1: float, beta2: float):
     if not (dyn.is_cuda and dyn.dtype == torch.float32 and dyn.numel() >= 4 and dyn.is_contiguous()):
         raise RuntimeError("adam_advance: dyn must be four contiguous fp32 values on the GPU")
     check(lib.dvae_adam_advance_f32(_p(dyn), float(beta1), float(beta2), _stream()), 'adam_advance')
+
+
+# ---------------------------------------------------------------------------- launch trace (benchmarks)
+def trace_begin(max_launches: int = 1 << 16):
+    """From here to trace_collect() every kernel launch of the library is timed with two events on its
+    stream and recorded with its symbol and declared algorithmic work.  Not under graph capture."""
+    check(lib.dvae_trace_begin(int(max_launches)), 'trace_begin')
+
+
+def trace_collect():
+    """Ends the trace; list of (kernel symbol, milliseconds, work, unit) with unit 1 = FLOP, 2 = byte,
+    0 = none declared.  Waits for the traced launches to finish."""
+    n = lib.dvae_trace_end()
+    name = ctypes.create_string_buffer(512)
+    ms, work, unit = ctypes.c_float(), ctypes.c_double(), ctypes.c_int()
+    out = []
+    for i in range(n):
+        check(lib.dvae_trace_read(i, name, 512, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(unit)), 'trace_read')
+        out.append((name.value.decode(), float(ms.value), float(work.value), int(unit.value)))
+    return out

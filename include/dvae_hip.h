@@ -355,6 +355,21 @@ int dvae_adam_step_f32(int64_t n, float* const* params, const float* const* grad
                        const float* grad_coef, const float* dyn, dvae_stream_t stream);
 int dvae_adam_advance_f32(float* dyn, double beta1, double beta2, dvae_stream_t stream);
 
+/* ---- launch tracing for benchmarks.  No counterpart in the reference (it times whole calls with a host
+ *      clock, evaluation/metrics.py:143-177).  Between dvae_trace_begin and dvae_trace_end every kernel
+ *      launch of the library is bracketed by two events on the stream it is launched on and recorded with
+ *      its symbol (demangled, as rocprofv3 prints it) and the algorithmic work its launcher declares:
+ *      FLOPs of a GEMM-shaped kernel (2*M*N*K of the layer, no padding), bytes an HBM-bound kernel must
+ *      read and write once; unit 0 = no declaration (helper kernels).  At most max_launches records are
+ *      kept.  dvae_trace_end returns the number recorded; dvae_trace_read waits for record i's events
+ *      and returns its duration in milliseconds.  Do not trace under stream capture. */
+#define DVAE_TRACE_UNIT_NONE 0
+#define DVAE_TRACE_UNIT_FLOP 1
+#define DVAE_TRACE_UNIT_BYTE 2
+int dvae_trace_begin(int64_t max_launches);
+int64_t dvae_trace_end(void);
+int dvae_trace_read(int64_t i, char* name, int64_t name_cap, float* ms, double* work, int* unit);
+
 #ifdef __cplusplus
 }
 #endif

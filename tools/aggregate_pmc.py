@@ -15,40 +15,8 @@ from collections import defaultdict
 
 
 def bench_label(name):
-    """the label bench.py's kernel table uses for a kernel symbol (None when it has no single one)"""
-    m = re.match(r'void conv_fwd_kernel<Tile<\d+, (\d+), .*?>, (\d), (true|false), (true|false), (true|false)>',
-                 name)
-    if m:       # <tile, mode, single input channel, bf16 operands, fused BatchNorm-backward statistics>
-        return f"conv_fwd_kernel<T{m.group(1)},{'deconv' if m.group(2) == '1' else 'conv'}" \
-               f"{',c1' if m.group(3) == 'true' else ''}{',bnstat' if m.group(5) == 'true' else ''}>"
-    m = re.match(r'void (deconv|conv)_rows_kernel<(\d+), (\d+), \d+, (true|false), (true|false)(?:, (true|false))?>', name)
-    if m:
-        return f"{m.group(1)}_rows_kernel<{m.group(2)},{m.group(3)}{',bnstat' if m.group(5) == 'true' else ''}" \
-               f"{',bnin' if m.group(6) == 'true' else ''}>"
-    m = re.match(r'void conv_c1_kernel<\d+, (true|false)>', name)
-    if m:
-        return 'conv_c1_kernel' + (',bnstat' if m.group(1) == 'true' else '')
-    m = re.match(r'void deconv_rows8_kernel<(\d+), \d+, (true|false), (true|false)>', name)
-    if m:
-        return f"deconv_rows8_kernel<{m.group(1)}{',bnstat' if m.group(3) == 'true' else ''}>"
-    if name.startswith('void wgrad_img4_kernel<'):
-        return 'wgrad_img4_kernel'
-    if name.startswith('void wgrad_rows8_kernel<'):
-        return 'wgrad_rows8_kernel'
-    m = re.match(r'void wgrad_rows_kernel<(\d+), (\d+),', name)
-    if m:
-        return f'wgrad_rows_kernel<{m.group(1)},{m.group(2)}>'
-    m = re.match(r'void conv_wgrad_kernel<Tile<(\d+), (\d+), .*?>, (true|false)>', name)
-    if m:
-        return f'conv_wgrad_kernel<T{m.group(1)}x{m.group(2)}>'
-    m = re.match(r'void gemm_kernel<Tile<.*?>, (\d), (?:\d|true|false)>', name)
-    if m:
-        return f"gemm_kernel<{('nt', 'nn', 'tn')[int(m.group(1))]}>"
-    m = re.match(r'void small_gemm_kernel<(\d), (true|false)>', name)
-    if m:
-        return f"small_gemm_kernel<{('nt', 'nn', 'tn')[int(m.group(1))]}>"
-    m = re.match(r'(?:void )?(\w+)', name)
-    return m.group(1) if m else None
+    """the key bench.py's kernel table uses: the demangled symbol without return type and parameter list"""
+    return re.sub(r'\(.*\)$', '', name).replace('void ', '').strip()
 
 
 def main():
