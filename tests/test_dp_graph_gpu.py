@@ -29,8 +29,12 @@ def _clips(B, T, seed):
 
 
 def _via_host(t, collective):
-    """run a gloo collective on a host copy of a device tensor (gloo's own device-tensor path proved
-    unreliable with two ranks on one GPU) and return the result on the device"""
+    """run a gloo collective on a host copy of a device tensor and return the result on the device (gloo's
+    own device-tensor path stalls with two ranks on one GPU; DP_TEST_DEVICE_COLLECTIVES=1 selects it, for
+    diagnosis: see the __main__ block)"""
+    if os.environ.get('DP_TEST_DEVICE_COLLECTIVES') == '1':
+        collective(t)
+        return t
     h = t.detach().cpu()
     collective(h)
     return h.to(t.device)
@@ -40,6 +44,9 @@ def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'disentangled-vae_amd'))
     torch.cuda.set_device(0)
+    if os.environ.get('DP_TEST_DEVICE_COLLECTIVES') == '1':
+        import faulthandler                                 # where is every thread when nothing moves?
+        faulthandler.dump_traceback_later(45, exit=True, file=sys.stderr)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import models
     from hipvae import losses, rng
@@ -119,3 +126,17 @@ def test_two_rank_graphed_step_matches_plain_averaging(tmp_path):
     # and the ranks did influence each other: rank 1's batches moved rank 0's parameters
     moved = max((r0['graph'][k] - r1['graph'][k]).abs().max().item() for k in r0['graph'] if 'running_mean' in k)
     assert moved > 0
+
+
+if __name__ == '__main__':
+    # diagnosis of the stall of gloo's device-tensor collectives with two ranks on one GPU:
+    #   DP_TEST_DEVICE_COLLECTIVES=1 DP_TEST_TRACE=1 python tests/test_dp_graph_gpu.py
+    # every collective then runs on the device tensor itself; after 45 s without finishing, each rank
+    # prints the Python stack of all its threads and exits
+    import tempfile
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, tempfile.mkdtemp()), nprocs=2, join=True)
+    print('finished without a stall')
