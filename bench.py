@@ -361,7 +361,7 @@ def main():
         'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': dtype_label, 'data': 'synthetic',
         'config': {'workload': f"{cfg['name']} ({args.config}) {args.mode} step, beta=4, {T}x{size}x{size} clips, "
-                               f"batch {B}/GPU, {prec_label}, {('batches from pinned host memory (' + args.host_batches + '), ') if args.host_batches else ''}{('hipGraph replay' + (' (backward graph, one all-reduce, update graph)' if use_dp else '')) if use_graph else 'eager launches'}",
+                               f"batch {B}/GPU, {prec_label}, {('batches from pinned host memory (' + args.host_batches + '), ') if args.host_batches else ''}{('hipGraph replay' + (' (decoder-side backward graph, all-reduce of its gradients beside the encoder-side backward graph, all-reduce of the rest, update graph)' if use_dp else '')) if use_graph else 'eager launches'}",
                    'global_batch': B * world, 'params': n_params,
                    'parallelism': f'dp{world}'},
     }
@@ -370,7 +370,7 @@ def main():
 
     if use_dp:
         result['rccl_world_size'] = dist.get_world_size()
-        result['config']['collective'] = ('one all-reduce (AVG) of the flat fp32 gradient buffer per step over RCCL'
+        result['config']['collective'] = ('two all-reduces (AVG) per step over RCCL on a side stream: decoder-side gradients while the encoders are still in backward, then the rest'
                                           if use_graph else 'bucketed all-reduces (AVG) over RCCL, overlapped with backward')
     gf = GFLOP_PER_CLIP.get(args.config)
     whole = None

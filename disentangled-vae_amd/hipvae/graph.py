@@ -98,78 +98,92 @@ def broadcast_flat(tensors, group=None, src: int = 0):
 class GraphedDataParallelStep(GraphedTrainStep):
     """The captured step for one replica of a data-parallel job (one process per GPU).
 
-    Two graphs with the gradient all-reduce between them: graph A is zero_grad + forward + loss +
-    backward and one multi-tensor copy of the gradients into a flat buffer; the flat buffer is averaged
-    over the ranks by ONE eager all-reduce (RCCL when the backend is 'nccl'); graph B is clip + Adam
-    reading the averaged gradients in place (p.grad are views of the flat buffer).  Compared with the
-    eager path (hipvae.parallel.GradSync: bucketed all-reduces launched from autograd hooks, overlapped
-    with backward) this gives up the overlap -- 52 MB per step for the DisentangledVAE, a fraction of a
-    millisecond over xGMI -- and removes the host from the step: the eager step is bound by Python
-    launch overhead as soon as several ranks share a node's cores.  Semantics are GradSync's:
-    parameters and buffers broadcast from rank 0, gradients averaged before clipping, BatchNorm
-    statistics per rank."""
+    Three graphs with the gradient all-reduces between them (hipvae.parallel.StagedGrads):
+      graph A1  zero_grad + forward + loss + backward of the loss and the decoder, down to the model's
+                stage_boundary, and one multi-tensor copy of those gradients into run 0 of the flat buffer;
+      all-reduce of run 0, on the communication stream: it travels while
+      graph A2  (backward of the encoders, gradients copied into run 1) runs on the compute stream;
+      all-reduce of run 1;
+      graph B   clip + Adam reading the averaged gradients in place (p.grad are views of the flat buffer).
+    No collective is captured.  Compared with the eager path (GradSync: bucketed all-reduces launched from
+    autograd hooks) the host issues three replays and two collectives per step instead of several hundred
+    launches, which matters as soon as several ranks share a node's cores.  Semantics are GradSync's:
+    parameters and buffers broadcast from rank 0, gradients averaged before clipping, BatchNorm statistics
+    per rank."""
 
     def __init__(self, model, optimizer, loss_of, example_video, gradient_clip: float = 0.0, warmup: int = 2,
                  process_group=None, broadcast_parameters: bool = True):
+        from .parallel import StagedGrads
         if not dist.is_initialized():
             raise RuntimeError("GraphedDataParallelStep needs an initialised torch.distributed process group")
         self.group = process_group
         self.world = dist.get_world_size(process_group)
-        self.use_avg = dist.get_backend(process_group) == 'nccl'
-        self.params = [p for p in model.parameters() if p.requires_grad]
         if broadcast_parameters:
             broadcast_flat(list(model.parameters()) + list(model.buffers()), process_group)
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.params[0].device)
-        self.views, off = [], 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
-        super().__init__(model, optimizer, loss_of, example_video, gradient_clip, warmup)
+        self.staged = self._make_staged([p for p in model.parameters() if p.requires_grad], process_group)
+        self.params = self.staged.params
+        super().__init__(model, optimizer, loss_of, example_video, gradient_clip, max(warmup, 1))
 
-    def _backward_part(self):
-        self.opt.zero_grad(set_to_none=True)
-        losses = self.loss_of(self.model, self.static_video)
-        losses['total_loss'].backward()
-        have = [i for i, p in enumerate(self.params) if p.grad is not None]
-        if len(have) != len(self.params):
-            self.flat.zero_()
-        torch._foreach_copy_([self.views[i] for i in have], [self.params[i].grad for i in have])
-        return losses
+    def _make_staged(self, params, process_group):
+        from .parallel import StagedGrads
+        return StagedGrads(params, process_group)
 
-    def _reduce(self):
-        dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM, group=self.group)
-        if not self.use_avg:
-            self.flat.div_(self.world)
+    @property
+    def flat(self):
+        return self.staged.flat
+
+    @property
+    def views(self):
+        return [self.staged.views[id(p)] for p in self.params]
+
+    def _stage1(self):
+        def run():
+            losses = self.loss_of(self.model, self.static_video)
+            return losses, losses['total_loss']
+        return self.staged.stage1(run)
 
     def _update_part(self):
-        for p, v in zip(self.params, self.views):
-            p.grad = v
+        self.staged.finish()
         if self.clip > 0:
             self.opt.clip_grad_norm_(self.clip, fold_into_step=True)
         self.opt.step()
 
-    def _step(self):              # the eager warm-up steps: the same sequence, collective included
-        losses = self._backward_part()
-        self._reduce()
+    def _step(self):              # the eager warm-up steps: the same sequence, collectives included
+        losses = self._stage1()
+        self.staged.reduce(0)
+        self.staged.stage2()
+        self.staged.reduce(1)
         self._update_part()
         return losses
 
     def _capture(self):
         # thread-local capture mode: the process group's watchdog thread polls events of finished
-        # collectives while this thread captures, which the default (global) mode may refuse
+        # collectives while this thread captures, which the default (global) mode may refuse.  The three
+        # graphs share one memory pool and are always replayed in this order.
+        torch.cuda.current_stream().wait_stream(self.staged.comm_stream)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-            self.losses = self._backward_part()
+            self.losses = self._stage1()
+        self.graph_stage2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_stage2, pool=self.graph.pool(), capture_error_mode='thread_local'):
+            self.staged.stage2()
         self.graph_update = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_update, pool=self.graph.pool(), capture_error_mode='thread_local'):
-            self._update_part()
+            # (finish() makes the capturing stream wait for the communication stream: outside capture)
+            for p in self.staged.order:
+                p.grad = self.staged.views[id(p)]
+            if self.clip > 0:
+                self.opt.clip_grad_norm_(self.clip, fold_into_step=True)
+            self.opt.step()
 
     def __call__(self, video: torch.Tensor):
         self.static_video.copy_(video, non_blocking=True)
         self.opt.sync_device_lr()
         self.graph.replay()
-        self._reduce()
+        self.staged.reduce(0)
+        self.graph_stage2.replay()
+        self.staged.reduce(1)
+        torch.cuda.current_stream().wait_stream(self.staged.comm_stream)
         self.graph_update.replay()
         self.opt.note_replayed_step()
         return self.losses

@@ -142,3 +142,134 @@ class GradSync:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+# =================================================================================================
+# Backward in two stages, so that the first stage's gradients can travel while the second computes.
+# =================================================================================================
+_BOUNDARY = None          # list of (tensors above the cut, detached leaves below it) while a staged step records
+
+
+def stage_boundary(*tensors: torch.Tensor):
+    """Called by a model between its encoder and its decoder.  Outside a staged step (the normal case) it
+    returns its arguments.  Inside one it cuts the autograd graph there: the tensors are replaced by
+    detached leaves, backward from the loss stops at them (stage 1: loss and decoder, whose parameter
+    gradients are then complete), and StagedGrads.stage2 later continues from the cut with the leaves'
+    gradients (encoders).  Values are unchanged either way."""
+    if _BOUNDARY is None or not torch.is_grad_enabled():
+        return tensors
+    leaves = tuple(t.detach().requires_grad_(True) if t.requires_grad else t for t in tensors)
+    _BOUNDARY.append((tensors, leaves))
+    return leaves
+
+
+class StagedGrads:
+    """One replica's gradients of a data-parallel step in ONE flat buffer made of two runs: the parameters
+    whose gradient is complete once backward has reached the model's stage_boundary (run 0: decoder side),
+    and the rest (run 1: encoder side).  Each run is averaged over the ranks by one all-reduce, launched on
+    a side stream as soon as the run is filled, so run 0 travels while stage 2 computes.  p.grad of every
+    parameter ends up as a view of the reduced buffer.  Which parameter belongs to which run is found on
+    the first step (it is a property of the model) and fixed afterwards; a model without a boundary has
+    everything in run 0.  The three phases are separate methods so that a caller can capture each as its
+    own graph and issue the collectives between the replays."""
+
+    def __init__(self, params: List[torch.nn.Parameter], process_group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("StagedGrads needs an initialised torch.distributed process group")
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.use_avg = dist.get_backend(process_group) == 'nccl'
+        self.params = [p for p in params if p.requires_grad]
+        self.device = self.params[0].device
+        self.on_gpu = self.device.type == 'cuda'
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self.flat = None
+        self.runs = None              # [(lo, hi)] of the two runs in the flat buffer
+        self.order = None             # parameters in flat-buffer order
+        self.views = None
+        self._cut = None
+        self._first = None            # ids of the parameters in run 0
+
+    # ---- layout -------------------------------------------------------------------------------
+    def _lay_out(self, first: List[torch.nn.Parameter]):
+        ids = {id(p) for p in first}
+        self._first = ids
+        self.order = [p for p in self.params if id(p) in ids] + [p for p in self.params if id(p) not in ids]
+        n0 = sum(p.numel() for p in self.order if id(p) in ids)
+        n = sum(p.numel() for p in self.order)
+        self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.device)
+        self.runs = [(0, n0), (n0, n)]
+        self.views, off = {}, 0
+        for p in self.order:
+            self.views[id(p)] = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def _fill(self, run: int):
+        """gradients of one run into the flat buffer (one multi-tensor copy); missing ones count as zero"""
+        ps = [p for p in self.order if (id(p) in self._first) == (run == 0)]
+        have = [p for p in ps if p.grad is not None and p.grad.data_ptr() != self.views[id(p)].data_ptr()]
+        for p in ps:
+            if p.grad is None:
+                self.views[id(p)].zero_()
+        if have:
+            torch._foreach_copy_([self.views[id(p)] for p in have], [p.grad for p in have])
+
+    # ---- the three phases -----------------------------------------------------------------------
+    def stage1(self, total_loss_of):
+        """total_loss_of() runs forward + loss and returns (whatever the caller wants back, total loss).
+        Backward from the loss down to the boundary; run 0 filled."""
+        global _BOUNDARY
+        for p in self.params:
+            p.grad = None
+        _BOUNDARY = []
+        try:
+            result, total = total_loss_of()
+        finally:
+            self._cut, _BOUNDARY = _BOUNDARY, None
+        total.backward()
+        if self.flat is None:
+            self._lay_out([p for p in self.params if p.grad is not None] if self._cut else list(self.params))
+        self._fill(0)
+        return result
+
+    def stage2(self):
+        """Backward from the boundary through the rest of the model; run 1 filled."""
+        above, grads = [], []
+        for tensors, leaves in self._cut or []:
+            for t, leaf in zip(tensors, leaves):
+                if leaf is not t and leaf.grad is not None:
+                    above.append(t)
+                    grads.append(leaf.grad)
+        self._cut = None
+        if above:
+            torch.autograd.backward(above, grads)
+        self._fill(1)
+
+    def reduce(self, run: int):
+        """Average one run over the ranks; on a GPU the collective is ordered after what the current stream
+        has been given so far and runs on the side stream."""
+        lo, hi = self.runs[run]
+        if hi == lo:
+            return
+        buf = self.flat[lo:hi]
+        op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+        if self.on_gpu:
+            self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.comm_stream):
+                self._all_reduce(buf, op)
+                if not self.use_avg:
+                    buf.div_(self.world)
+        else:
+            self._all_reduce(buf, op)
+            if not self.use_avg:
+                buf.div_(self.world)
+
+    def _all_reduce(self, buf, op):
+        dist.all_reduce(buf, op=op, group=self.group)
+
+    def finish(self):
+        """The compute stream waits for both collectives; every p.grad becomes its slice of the buffer."""
+        if self.on_gpu:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        for p in self.order:
+            p.grad = self.views[id(p)]

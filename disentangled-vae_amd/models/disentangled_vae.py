@@ -10,6 +10,7 @@ import torch.nn as nn
 
 from hipvae import ops
 from hipvae.losses import disentangled_loss as compute_loss  # noqa: F401  (reference name)
+from hipvae.parallel import stage_boundary
 from .decoders import DisentangledDecoder
 from .encoders import ContentEncoder, MotionEncoder
 
@@ -50,6 +51,8 @@ class DisentangledVAE(nn.Module):
 
     def forward(self, video: torch.Tensor) -> Dict[str, torch.Tensor]:
         z_c, z_m, (mu_c, lv_c), (mu_m, lv_m) = self.encode(video)
+        # encoder | decoder + loss: where a data-parallel step cuts backward in two (a no-op otherwise)
+        z_c, z_m, mu_c, lv_c, mu_m, lv_m = stage_boundary(z_c, z_m, mu_c, lv_c, mu_m, lv_m)
         recon = self.decode(z_c, z_m, sequence_length=video.shape[1])
         return {'recon': recon, 'z_content': z_c, 'z_motion': z_m, 'mu_content': mu_c, 'logvar_content': lv_c,
                 'mu_motion': mu_m, 'logvar_motion': lv_m}

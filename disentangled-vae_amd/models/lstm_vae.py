@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from hipvae.losses import lstm_loss as compute_loss  # noqa: F401  (reference name)
+from hipvae.parallel import stage_boundary
 from .decoders import CNNDecoder, LSTMDecoder
 from .encoders import CNNEncoder, LSTMEncoder, VAEEncoder, reparameterize
 
@@ -46,6 +47,7 @@ class LSTMVAE(nn.Module):
 
     def forward(self, video: torch.Tensor):
         z, mu, logvar = self.encode(video)
+        z, mu, logvar = stage_boundary(z, mu, logvar)      # where a data-parallel step cuts backward in two
         return self.decode(z, sequence_length=video.shape[1]), z, mu, logvar
 
     def sample(self, num_samples: int = 1, device: torch.device = None, sequence_length: Optional[int] = None):

@@ -1,9 +1,9 @@
-"""Two data-parallel ranks on ONE GPU: the captured two-graph step (hipvae.graph.GraphedDataParallelStep)
+"""Two data-parallel ranks on ONE GPU: the captured three-graph step (hipvae.graph.GraphedDataParallelStep:
+decoder-side backward, reduction of its gradients, encoder-side backward, reduction of the rest, update)
 against the plain statement of its semantics (broadcast from rank 0; every step: backward, all-reduce and
 average every gradient, clip, Adam), from the same initialisation and on the same per-rank batches.
 The collectives themselves run on host copies (gloo; RCCL refuses two ranks on one device): what is
-checked is the sequence backward graph -> reduction of the flat gradient buffer -> update graph with
-more than one rank, not a backend.  The gradients of both ranks really are averaged between the two
+checked is the sequence of graphs and reductions with more than one rank, not a backend.  The gradients of both ranks really are averaged between the two
 graphs, both ranks take the same step, and that step is the plain one's."""
 import os
 import socket
@@ -87,15 +87,27 @@ def _worker(rank, world, port, out_dir):
                 opt.clip_grad_norm_(1.0, fold_into_step=True)
                 opt.step()
         else:
+            from hipvae.parallel import StagedGrads
+
+            class HostStaged(StagedGrads):
+                def _all_reduce(self, buf, op):
+                    buf.copy_(_via_host(buf, dist.all_reduce))
+
             class HostReducedStep(GraphedDataParallelStep):
-                def _reduce(self):
-                    self.flat.copy_(_via_host(self.flat, dist.all_reduce) / self.world)
+                def _make_staged(self, params, process_group):
+                    return HostStaged(params, process_group)
 
             for t in list(m.parameters()) + list(m.buffers()):       # (the class would broadcast on the device)
                 if t.is_floating_point():
                     t.data.copy_(_via_host(t.data, lambda h: dist.broadcast(h, src=0)))
             step = HostReducedStep(m, opt, loss_of, batches[0], gradient_clip=1.0, broadcast_parameters=False)
             trace('captured')
+            lo, hi = step.staged.runs[0]
+            assert 0 < hi < step.staged.flat.numel()                 # both runs exist: the model has a boundary
+            first = {id(p) for p in step.staged.order[:sum(1 for p in step.staged.order if id(p) in step.staged._first)]}
+            names = {id(p): n for n, p in m.named_parameters()}
+            assert all(names[i].startswith('decoder.') for i in first)
+            assert all(n.startswith('decoder.') == (id(p) in first) for n, p in m.named_parameters())
             for v in batches:
                 step(v)
         torch.cuda.synchronize()
@@ -120,7 +132,8 @@ def test_two_rank_graphed_step_matches_plain_averaging(tmp_path):
             assert torch.equal(r0['graph'][k], r1['graph'][k]), k
             assert torch.equal(r0['eager'][k], r1['eager'][k]), k
         a, b = r0['eager'][k], r0['graph'][k]
-        # Adam's bias correction is computed on the device in fp32 under replay, on the host in fp64 otherwise
+        # the staged backward sums the contributions to a latent's gradient in another order than one
+        # backward pass does: last-bit differences, nothing at the level a missed reduction would show
         d = (a - b).abs().max().item()
         assert d <= 1e-6 + 1e-5 * a.abs().max().item(), (k, d)
     # and the ranks did influence each other: rank 1's batches moved rank 0's parameters

@@ -88,3 +88,92 @@ def test_gradsync_two_ranks_gloo(tmp_path):
         with torch.no_grad():
             for k, p in net.named_parameters():
                 p -= 0.01 * avg[k]
+
+
+class CutNet(torch.nn.Module):
+    """encoder | decoder with the boundary the models of this package call between the two"""
+
+    def __init__(self):
+        super().__init__()
+        self.enc = torch.nn.Linear(8, 6)
+        self.enc2 = torch.nn.Linear(8, 6)
+        self.dec = torch.nn.Linear(6, 4)
+        self.unused = torch.nn.Parameter(torch.ones(3))
+
+    def forward(self, x):
+        from hipvae.parallel import stage_boundary
+        z, mu = torch.tanh(self.enc(x)), self.enc2(x)
+        z, mu = stage_boundary(z, mu)
+        # the loss uses the latent both through the decoder and directly, like the KL / independence terms
+        return self.dec(z).pow(2).sum() + 0.1 * mu.pow(2).sum() + 0.05 * (z * mu).sum()
+
+
+def _staged_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    'disentangled-vae_amd'))
+    from hipvae.parallel import StagedGrads
+    torch.manual_seed(7)                        # same initialisation on both ranks (broadcast is tested above)
+    net = CutNet()
+    staged = StagedGrads(list(net.parameters()))
+    events, states = [], []
+    orig = staged._all_reduce
+    staged._all_reduce = lambda buf, op: (events.append(('reduce', buf.numel())), orig(buf, op))
+    for step in range(3):
+        g = torch.Generator().manual_seed(10 * step + rank)
+        x = torch.randn(5, 8, generator=g)
+        staged.stage1(lambda: (None, net(x)))
+        # after stage 1 the decoder's gradients are complete and nothing has reached the encoders
+        assert net.dec.weight.grad is not None and net.enc.weight.grad is None and net.enc2.weight.grad is None
+        events.append(('stage1',))
+        staged.reduce(0)
+        staged.stage2()
+        assert net.enc.weight.grad is not None and net.enc2.weight.grad is not None
+        events.append(('stage2',))
+        staged.reduce(1)
+        staged.finish()
+        assert all(p.grad.data_ptr() == staged.views[id(p)].data_ptr() for p in staged.params)
+        states.append({k: p.grad.clone() for k, p in net.named_parameters()})
+        with torch.no_grad():
+            for p in net.parameters():
+                p -= 0.01 * p.grad
+    n_dec = sum(p.numel() for p in net.dec.parameters())
+    n_all = sum(p.numel() for p in net.parameters())
+    assert events[:4] == [('stage1',), ('reduce', n_dec), ('stage2',), ('reduce', n_all - n_dec)], events[:4]
+    torch.save({'grads': states}, os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_staged_backward_two_ranks_gloo(tmp_path):
+    """hipvae.parallel.StagedGrads: backward cut at the model's stage boundary, the decoder-side run of the
+    flat buffer reduced between the two stages, the encoder-side run after the second; the averaged
+    gradients equal those of one uncut backward pass per rank, averaged."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_staged_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / 'rank0.pt')
+    r1 = torch.load(tmp_path / 'rank1.pt')
+    for s0, s1 in zip(r0['grads'], r1['grads']):
+        for k in s0:
+            assert torch.equal(s0[k], s1[k]), k
+    torch.manual_seed(7)
+    net = CutNet()
+    for step in range(3):
+        grads = []
+        for rank in range(world):
+            g = torch.Generator().manual_seed(10 * step + rank)
+            x = torch.randn(5, 8, generator=g)
+            net.zero_grad()
+            net(x).backward()                   # no staged step is recording: the boundary is the identity
+            grads.append({k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p))
+                          for k, p in net.named_parameters()})
+        avg = {k: (grads[0][k] + grads[1][k]) / 2 for k in grads[0]}
+        for k in avg:
+            torch.testing.assert_close(r0['grads'][step][k], avg[k], rtol=1e-6, atol=1e-7)
+        assert float(r0['grads'][step]['unused'].abs().sum()) == 0.0
+        with torch.no_grad():
+            for k, p in net.named_parameters():
+                p -= 0.01 * avg[k]
