@@ -360,3 +360,282 @@ extern "C" int dvae_skinny_gemm_nt_f32(const float* a, int64_t ld_a, const float
   DVAE_LAUNCH_CHECK("skinny_gemm_nt");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Whole recurrence in ONE launch (forward).
+//
+// The batch rows are independent, so the work splits into groups of 32 rows, and a group into H/8
+// workgroups that each own eight hidden units (4 x 8 = 32 gate columns).  A workgroup keeps its slice of
+// the recurrent weights in registers for all T steps (each of its eight waves holds 32 columns x H/8 of
+// the K dimension in MFMA operand layout), keeps the cell state of its 32 x 8 elements in registers, and
+// per step needs only the group's previous hidden state [32 x H] from the other workgroups of its group.
+// That hand-off goes through global memory inside the launch:
+//   producer  four waves store the new 32 x 8 block of h write-through (agent-scope atomic stores: one
+//             256-byte run per wave instruction, whole 128-byte lines), each wave drains its stores
+//             (s_waitcnt vmcnt(0)) and one lane of it adds 1 to the group's arrival counter;
+//   consumer  one lane polls the counter with agent-scope loads until all 4*(H/8) arrivals of the step are
+//             in, the workgroup passes a barrier, and then every wave fetches its part of h with
+//             write-through-coherent (sc1) 16-byte loads only.
+// Two buffers alternate: a workgroup can only write step t+1 after every workgroup of its group has
+// written step t, i.e. has finished reading step t-1.  Groups never wait for each other.  Workgroups of a
+// group are numbered eight apart so that they tend to share an XCD's L2 (speed only).  Every wait is
+// bounded: after LSTM_SEQ_TIMEOUT_TICKS without progress a workgroup raises the launch's timeout word
+// and leaves; the others see the word and leave too, so the grid always drains.  All workgroups of a
+// launch must be resident together: the host launches at most one per compute unit.
+// ------------------------------------------------------------------------------------------------
+#define SEQ_WAVES 8
+#define SEQ_MAX_CHAINS 2
+#define SEQ_CNT_STRIDE 64                    // unsigned words between the counters of two groups (256 B)
+#define LSTM_SEQ_TIMEOUT_TICKS 4000000LL     // of the 100 MHz wall clock: 40 ms
+
+struct LstmSeqChain {
+  const float* xproj;        // [T][B][4H] input projections without bias, or nullptr
+  const float* w_rec;        // [4H][H]
+  const float* b_a;          // [4H] or nullptr
+  const float* b_b;          // [4H] or nullptr (comes with b_a)
+  const float* h_init; int64_t ld_hinit;     // [B][..] or nullptr (zeros)
+  const float* c_init; int64_t ld_cinit;     // [B][..] or nullptr (zeros)
+  float* gates;              // [T][B][4H] activated gates, out
+  float* hseq; int64_t ld_h; int64_t step_h; // h of step t at hseq + t*step_h + b*ld_h + j
+  float* cseq;               // [T][B][H]
+  int reverse;               // walk t = T-1 .. 0
+};
+
+struct LstmSeqArgs {
+  LstmSeqChain ch[SEQ_MAX_CHAINS];
+  int nchains;
+  int T;
+  int64_t B;
+  int H;
+  int groups_per_chain;      // ceil(B / 32)
+  unsigned* sync;            // [0] timeout word, then one arrival counter per group, SEQ_CNT_STRIDE apart
+  float* xch;                // exchange: [group][2][H/8 slices][32 rows][8]
+};
+
+typedef __attribute__((address_space(1))) unsigned gu32_t;
+
+__device__ __forceinline__ f32x4 load_x4_sc1(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+template <int KW>      // K per wave = H / 8: 16, 32 or 64
+__global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_seq_fwd_kernel(LstmSeqArgs g) {
+  __shared__ float red[SEQ_WAVES * 32 * KS_RED_LD];
+  __shared__ int s_abort;
+  constexpr int NQ = KW / 2;                 // MFMAs per wave and step; also units per lane half
+  const int H = g.H, NS = H / 8;
+  const int ngroups = g.nchains * g.groups_per_chain;
+  // workgroups of one group are eight apart in blockIdx
+  const int per8 = 8 * NS;
+  const int group = (int)(blockIdx.x % 8) + 8 * (int)(blockIdx.x / per8);
+  const int slice = (int)(blockIdx.x % per8) / 8;
+  if (group >= ngroups) return;
+  const LstmSeqChain& c = g.ch[group / g.groups_per_chain];
+  const int64_t b0 = (int64_t)(group % g.groups_per_chain) * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  unsigned* const tmo = g.sync;
+  unsigned* const cnt = g.sync + SEQ_CNT_STRIDE * (1 + group);
+  float* const xch = g.xch + (int64_t)group * 2 * H * 32;
+  if (threadIdx.x == 0) s_abort = 0;
+
+  // this wave's K range and this lane's units in it: unit(i) = kbase + NQ*hh + i
+  const int kbase = wave * KW + NQ * hh;
+  // recurrent weights -> registers: B operand of MFMA i is W[gate row of column l31][unit(i)]
+  const int64_t wrow = (int64_t)(l31 >> 3) * H + slice * 8 + (l31 & 7);
+  float wreg[NQ];
+  {
+    const float* wp = c.w_rec + wrow * H + kbase;
+#pragma unroll
+    for (int q = 0; q < NQ / 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wp + 4 * q);
+      wreg[4 * q + 0] = v[0]; wreg[4 * q + 1] = v[1]; wreg[4 * q + 2] = v[2]; wreg[4 * q + 3] = v[3];
+    }
+  }
+  // cell-update role (threads 0..255): row bl, unit jj; the cell state stays in a register
+  const int bl = threadIdx.x >> 3, jj = threadIdx.x & 7;
+  const bool cell = threadIdx.x < 256;
+  const int64_t b = b0 + bl, j = (int64_t)slice * 8 + jj;
+  const bool bok = cell && b < g.B;
+  float bias[4] = {0.f, 0.f, 0.f, 0.f};
+  float cstate = 0.f;
+  if (cell) {
+    if (c.b_a) {
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt) bias[gt] = c.b_a[gt * H + j] + c.b_b[gt * H + j];
+    }
+    if (bok && c.c_init) cstate = c.c_init[b * c.ld_cinit + j];
+  }
+  const int64_t arow = b0 + l31;
+  const bool arow_ok = arow < g.B;
+  __syncthreads();
+
+  for (int step = 0; step < g.T; ++step) {
+    const int t = c.reverse ? g.T - 1 - step : step;
+    // operands of the cell update that do not depend on the hand-off: requested before the wait
+    float xp[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bok && c.xproj) {
+      const float* xr = c.xproj + ((int64_t)t * g.B + b) * 4 * H + j;
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt) xp[gt] = xr[gt * H];
+    }
+    f32x4 av[NQ / 4];
+    bool have_h = true;
+    if (step == 0) {
+      if (c.h_init && arow_ok) {
+        const float* hp = c.h_init + arow * c.ld_hinit + kbase;
+#pragma unroll
+        for (int q = 0; q < NQ / 4; ++q) av[q] = *reinterpret_cast<const f32x4*>(hp + 4 * q);
+      } else {
+#pragma unroll
+        for (int q = 0; q < NQ / 4; ++q) av[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        have_h = c.h_init != nullptr;
+      }
+    } else {
+      if (threadIdx.x == 0) {
+        const unsigned target = 4u * (unsigned)NS * (unsigned)step;
+        const long long t0 = wall_clock64();
+        bool ok = true;
+        while (__hip_atomic_load((gu32_t*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(1);
+          if (wall_clock64() - t0 > LSTM_SEQ_TIMEOUT_TICKS ||
+              __hip_atomic_load((gu32_t*)tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            ok = false;
+            break;
+          }
+        }
+        if (!ok) {
+          __hip_atomic_store((gu32_t*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_abort = 1;
+        }
+      }
+      __syncthreads();
+      if (s_abort) return;
+      // h of the previous step: unit u lives in slice u/8 at [row][u%8]
+      const float* src = xch + (int64_t)((step - 1) & 1) * H * 32;
+#pragma unroll
+      for (int q = 0; q < NQ / 4; ++q) {
+        const int u = kbase + 4 * q;
+        av[q] = load_x4_sc1(src + ((int64_t)(u >> 3) * 32 + l31) * 8 + (u & 7));
+      }
+      // the loads above are invisible to the compiler's wait counters: wait here, and make every use of
+      // the registers depend on this statement
+      if constexpr (NQ / 4 == 2)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(av[1]) : : "memory");
+      else if constexpr (NQ / 4 == 4)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]) : : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7])
+                     : : "memory");
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (have_h) {
+#pragma unroll
+      for (int q = 0; q < NQ / 4; ++q) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][0], wreg[4 * q + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][1], wreg[4 * q + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][2], wreg[4 * q + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][3], wreg[4 * q + 3], acc, 0, 0, 0);
+      }
+    }
+    ks_spill(red, acc, wave, lane);
+    __syncthreads();
+    if (cell) {
+      float pre[4];
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt) {
+        const int col = gt * 8 + jj;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < SEQ_WAVES; ++w) s += red[(w * 32 + bl) * KS_RED_LD + col];
+        pre[gt] = (s + xp[gt]) + bias[gt];
+      }
+      const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+      cstate = fg * cstate + ig * gg;
+      const float hn = og * tanhf(cstate);
+      if (step + 1 < g.T) {
+        // hand the new state to the group: [slice][row][8], one float per thread = 256 B per wave instruction
+        float* dst = xch + (int64_t)(step & 1) * H * 32 + ((int64_t)slice * 32 + bl) * 8 + jj;
+        __hip_atomic_store((__attribute__((address_space(1))) float*)dst, bok ? hn : 0.f, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (bok) {
+        float* go = c.gates + ((int64_t)t * g.B + b) * 4 * H;
+        go[0 * H + j] = ig;
+        go[1 * H + j] = fg;
+        go[2 * H + j] = gg;
+        go[3 * H + j] = og;
+        c.cseq[((int64_t)t * g.B + b) * H + j] = cstate;
+        c.hseq[(int64_t)t * c.step_h + b * c.ld_h + j] = hn;
+      }
+      if (step + 1 < g.T) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
+        if (lane == 0) __hip_atomic_fetch_add((gu32_t*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // (the next step's barrier behind the poll keeps `red` from being overwritten while it is read)
+  }
+}
+
+extern "C" int64_t dvae_lstm_seq_ws_floats(int64_t nchains, int64_t B, int64_t H) {
+  const int64_t groups = nchains * ceil_div64(B, 32);
+  return SEQ_CNT_STRIDE * (1 + groups) + groups * 2 * H * 32;
+}
+
+extern "C" int dvae_lstm_seq_supported(int64_t nchains, int64_t T, int64_t B, int64_t H) {
+  if (nchains < 1 || nchains > SEQ_MAX_CHAINS || T < 1 || B < 1) return 0;
+  if (H != 128 && H != 256 && H != 512) return 0;
+  // every workgroup must be resident at once: at most one per compute unit of the 256
+  return nchains * ceil_div64(B, 32) * (H / 8) <= 256;
+}
+
+extern "C" int dvae_lstm_seq_fwd_f32(int64_t nchains, const float* const* xproj, const float* const* w_rec,
+                                     const float* const* b_a, const float* const* b_b, const float* const* h_init,
+                                     int64_t ld_hinit, const float* const* c_init, int64_t ld_cinit,
+                                     float* const* gates, float* const* hseq, int64_t ld_h, int64_t step_h,
+                                     float* const* cseq, const int* reverse, int64_t T, int64_t B, int64_t H,
+                                     float* ws, dvae_stream_t stream) {
+  DVAE_REQUIRE(dvae_lstm_seq_supported(nchains, T, B, H),
+               "lstm_seq_fwd: unsupported shape (chains=%ld T=%ld B=%ld H=%ld): H must be 128, 256 or 512 and "
+               "chains*ceil(B/32)*(H/8) at most 256", (long)nchains, (long)T, (long)B, (long)H);
+  DVAE_REQUIRE(ws != nullptr && (((uintptr_t)ws) & 255) == 0, "lstm_seq_fwd: workspace must be 256-byte aligned");
+  LstmSeqArgs g;
+  g.nchains = (int)nchains; g.T = (int)T; g.B = B; g.H = (int)H;
+  g.groups_per_chain = (int)ceil_div64(B, 32);
+  for (int i = 0; i < nchains; ++i) {
+    LstmSeqChain& c = g.ch[i];
+    c.xproj = xproj ? xproj[i] : nullptr;
+    c.w_rec = w_rec[i];
+    c.b_a = b_a ? b_a[i] : nullptr;
+    c.b_b = b_b ? b_b[i] : nullptr;
+    c.h_init = h_init ? h_init[i] : nullptr; c.ld_hinit = ld_hinit;
+    c.c_init = c_init ? c_init[i] : nullptr; c.ld_cinit = ld_cinit;
+    c.gates = gates[i]; c.hseq = hseq[i]; c.ld_h = ld_h; c.step_h = step_h; c.cseq = cseq[i];
+    c.reverse = reverse ? reverse[i] : 0;
+    DVAE_REQUIRE(c.w_rec && c.gates && c.hseq && c.cseq, "lstm_seq_fwd: null argument (chain %d)", i);
+    DVAE_REQUIRE((c.b_a == nullptr) == (c.b_b == nullptr), "lstm_seq_fwd: biases come in pairs");
+    DVAE_REQUIRE(aligned16(c.w_rec) && (c.h_init == nullptr || (aligned16(c.h_init) && ld_hinit % 4 == 0)),
+                 "lstm_seq_fwd: w_rec and h_init must be 16-byte aligned, ld_hinit a multiple of 4");
+  }
+  const int groups = g.nchains * g.groups_per_chain;
+  g.sync = (unsigned*)ws;
+  g.xch = ws + SEQ_CNT_STRIDE * (1 + groups);
+  // arrival counters and the timeout word start every launch at zero
+  if (hipMemsetAsync(ws, 0, sizeof(unsigned) * SEQ_CNT_STRIDE * (1 + groups), ST(stream)) != hipSuccess) {
+    dvae_set_error("lstm_seq_fwd: clearing the counters failed: %s", hipGetErrorString(hipGetLastError()));
+    return -EIO;
+  }
+  const int NS = (int)(H / 8);
+  const unsigned nblocks = (unsigned)(8 * NS * ((groups + 7) / 8));
+  DVAE_WORK(2.0 * (double)nchains * T * B * 4 * H * H, DVAE_UNIT_FLOP);
+  if (H == 128) DVAE_LAUNCH((lstm_seq_fwd_kernel<16>), dim3(nblocks), dim3(64 * SEQ_WAVES), 0, ST(stream), g);
+  else if (H == 256) DVAE_LAUNCH((lstm_seq_fwd_kernel<32>), dim3(nblocks), dim3(64 * SEQ_WAVES), 0, ST(stream), g);
+  else DVAE_LAUNCH((lstm_seq_fwd_kernel<64>), dim3(nblocks), dim3(64 * SEQ_WAVES), 0, ST(stream), g);
+  DVAE_LAUNCH_CHECK("lstm_seq_fwd");
+  return 0;
+}

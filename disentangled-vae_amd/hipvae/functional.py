@@ -15,6 +15,7 @@ LeakyReLU is never materialised between conv layers: the conv kernel writes the 
 per-channel partial sums, a finalize kernel folds the statistics into (scale, shift), and the next
 kernel applies them while loading.
 """
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -24,6 +25,9 @@ from . import ops
 Tensor = torch.Tensor
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+# one launch per LSTM recurrence (weights resident, in-launch hand-off of the hidden state) where the
+# shape admits it; False selects one launch per time step everywhere
+USE_SEQ_KERNELS = os.environ.get('DVAE_SEQ_LSTM', '1') != '0'
 
 
 def _need_gpu(t: Tensor, what: str):
@@ -375,6 +379,15 @@ class LSTMEncoder(torch.autograd.Function):
             ws = [[w.detach() for w in weights[(l * D + d) * 4:(l * D + d) * 4 + 4]] for d in range(D)]
             xproj = [ops.gemm_nt(inp.view(T * B, I), ws[d][0].contiguous()).view(T, B, 4 * H) for d in range(D)]
             w_hh = [ws[d][1].contiguous() for d in range(D)]
+            if USE_SEQ_KERNELS and ops.lstm_seq_supported(D, T, B, H):
+                # the whole recurrence of both directions in one launch, recurrent weights in registers
+                ops.lstm_seq_fwd([dict(xproj=xproj[d], w_rec=w_hh[d], b_a=ws[d][2].contiguous(),
+                                       b_b=ws[d][3].contiguous(), gates=gates[d],
+                                       hseq=hseq[:, :, d * H:(d + 1) * H], cseq=cseq[d], reverse=(d == 1))
+                                  for d in range(D)], T, B, H)
+                layers.append((inp, hseq, cseq, gates))
+                inp = hseq
+                continue
             with _TwoLanes(x, D == 2) as lanes:
                 for i in range(T):
                     for d in range(D):
@@ -491,7 +504,8 @@ class LSTMDecoder(torch.autograd.Function):
         # a single layer is fed its own previous output: x_t == h_{t-1} for t > 0, so
         # x W_ih^T + h W_hh^T = h (W_ih + W_hh)^T and the step is H deep instead of 2H
         w_comb = (w[0] + w[1]) if (L == 1 and T > 1) else None
-        for t in range(T):
+        seq = w_comb is not None and USE_SEQ_KERNELS and ops.lstm_seq_supported(1, T - 1, B, H)
+        for t in range(1 if seq else T):
             for l in range(L):
                 h_prev = h0[:, l * H:(l + 1) * H] if t == 0 else hs[l, t - 1]
                 c_prev = c0[:, l * H:(l + 1) * H] if t == 0 else cs[l, t - 1]
@@ -505,6 +519,10 @@ class LSTMDecoder(torch.autograd.Function):
                     x = hs[l - 1, t]
                 ops.lstm_step_fwd(None, x, w[4 * l], h_prev, c_prev, w[4 * l + 1], w[4 * l + 2], w[4 * l + 3],
                                   gates[l, t], hs[l, t], cs[l, t])
+        if seq:
+            # steps 1 .. T-1 feed on their own previous output: one launch, W_ih + W_hh in registers
+            ops.lstm_seq_fwd([dict(w_rec=w_comb, b_a=w[2], b_b=w[3], h_init=hs[0, 0], c_init=cs[0, 0],
+                                   gates=gates[0, 1:], hseq=hs[0, 1:], cseq=cs[0, 1:])], T - 1, B, H)
         states = ops.permute3(hs[L - 1], (T, B, H), (1, 0, 2))         # [B, T, H]
         ctx.save_for_backward(h0, c0, init_c, hs, cs, gates, *weights)
         ctx.cfg = (B, T, L, H)

@@ -613,6 +613,46 @@ def skinny_gemm_nt(a: Tensor, wt: Tensor, out: Tensor, accumulate: bool):
                                       int(accumulate), _stream()), 'skinny_gemm_nt')
 
 
+def lstm_seq_supported(nchains: int, T: int, B: int, H: int) -> bool:
+    return bool(lib.dvae_lstm_seq_supported(nchains, T, B, H))
+
+
+def _ptr_array(ts):
+    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+def lstm_seq_fwd(chains, T: int, B: int, H: int):
+    """One launch for the whole recurrence of up to two independent chains.  Each chain is a dict with
+    w_rec [4H,H], gates [T,B,4H], hseq (a [T,B,>=H] view: row and step strides are taken from it), cseq
+    [T,B,H], and optionally xproj [T,B,4H], b_a / b_b [4H], h_init / c_init [B,H] views, reverse."""
+    n = len(chains)
+    get = lambda k: [c.get(k) for c in chains]
+    for c in chains:
+        _chk2(c.get('xproj'), c['w_rec'], c.get('b_a'), c.get('b_b'), c.get('h_init'), c.get('c_init'), c['gates'],
+              c['hseq'], c['cseq'])
+        assert c['w_rec'].is_contiguous() and c['gates'].is_contiguous() and c['cseq'].is_contiguous()
+        assert c['hseq'].shape[:2] == (T, B) and c['hseq'].stride(2) == 1
+        assert c.get('xproj') is None or c['xproj'].is_contiguous()
+    hs0 = chains[0]['hseq']
+    ld_h, step_h = hs0.stride(1), hs0.stride(0)
+    assert all(c['hseq'].stride(1) == ld_h and c['hseq'].stride(0) == step_h for c in chains)
+    hi = [c.get('h_init') for c in chains]
+    ci = [c.get('c_init') for c in chains]
+    assert all((h is None) == (hi[0] is None) for h in hi) and all((x is None) == (ci[0] is None) for x in ci)
+    ld_hi = 0 if hi[0] is None else hi[0].stride(0)
+    ld_ci = 0 if ci[0] is None else ci[0].stride(0)
+    assert all(h is None or (h.stride(0) == ld_hi and h.stride(1) == 1) for h in hi)
+    assert all(x is None or (x.stride(0) == ld_ci and x.stride(1) == 1) for x in ci)
+    ws = workspace(lib.dvae_lstm_seq_ws_floats(n, B, H), chains[0]['w_rec'].device, 'lstm_seq')
+    rev = (ctypes.c_int * n)(*[int(bool(c.get('reverse', False))) for c in chains])
+    opt = lambda k: None if all(v is None for v in get(k)) else _ptr_array(get(k))
+    check(lib.dvae_lstm_seq_fwd_f32(n, opt('xproj'), _ptr_array(get('w_rec')), opt('b_a'), opt('b_b'), opt('h_init'),
+                                    ld_hi, opt('c_init'), ld_ci, _ptr_array(get('gates')), _ptr_array(get('hseq')),
+                                    ld_h, step_h, _ptr_array(get('cseq')), rev, T, B, H, _p(ws), _stream()),
+          'lstm_seq_fwd')
+    return ws
+
+
 # ---------------------------------------------------------------------------- optimiser
 class TensorTable:
     """Host-side pointer/size arrays for the multi-tensor kernels, rebuilt only when pointers move."""

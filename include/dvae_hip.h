@@ -330,6 +330,29 @@ int dvae_skinny_gemm_nt_f32(const float* a, int64_t ld_a, const float* wt, int64
                             int64_t ld_out, int64_t B, int64_t N, int64_t K, int accumulate,
                             dvae_stream_t stream);
 
+/* ---- the whole recurrence of one LSTM layer in ONE launch (nn.LSTM over a sequence, models/encoders.py:145-161;
+ *      the autoregressive decoder loop, models/decoders.py:129-132,264-267, from its second step on, where a
+ *      single layer's input is its own previous output and x W_ih^T + h W_hh^T = h (W_ih + W_hh)^T).
+ *      Up to two independent chains per launch (the two directions of a bidirectional layer); host arrays
+ *      of nchains device pointers.  Per chain and step t (walked T-1..0 when reverse[c] != 0):
+ *        pre = [xproj[t]] + h_prev * w_rec^T + [b_a + b_b];   gates/c/h as in dvae_lstm_step_fwd_f32
+ *      xproj [T][B][4H] (NULL array or entry: none), w_rec [4H][H], h_init / c_init [B] rows with strides
+ *      ld_hinit / ld_cinit (NULL: zero state), outputs gates [T][B][4H], cseq [T][B][H] and h of step t at
+ *      hseq + t*step_h + b*ld_h.  The recurrent weights stay in registers for all T steps: a group of 32
+ *      batch rows is served by H/8 workgroups that exchange the hidden state through ws inside the launch.
+ *      All workgroups must be resident together, so dvae_lstm_seq_supported() admits H in {128, 256, 512}
+ *      and nchains*ceil(B/32)*(H/8) <= 256 only; otherwise -EINVAL (use the per-step calls).
+ *      ws: dvae_lstm_seq_ws_floats(nchains, B, H) floats, 256-byte aligned; ws[0] (read as unsigned) is
+ *      non-zero after the launch if a wait inside it ran into its 40 ms bound (outputs are then invalid).
+ *      Not to be run concurrently with another launch of itself unless both fit the chip together. */
+int dvae_lstm_seq_supported(int64_t nchains, int64_t T, int64_t B, int64_t H);
+int64_t dvae_lstm_seq_ws_floats(int64_t nchains, int64_t B, int64_t H);
+int dvae_lstm_seq_fwd_f32(int64_t nchains, const float* const* xproj, const float* const* w_rec,
+                          const float* const* b_a, const float* const* b_b, const float* const* h_init,
+                          int64_t ld_hinit, const float* const* c_init, int64_t ld_cinit, float* const* gates,
+                          float* const* hseq, int64_t ld_h, int64_t step_h, float* const* cseq, const int* reverse,
+                          int64_t T, int64_t B, int64_t H, float* ws, dvae_stream_t stream);
+
 /* ---- optimiser (torch.optim.Adam with L2 weight decay and nn.utils.clip_grad_norm_ as called at
  *      training/trainer.py:56-61,198-204).  Host arrays of n device pointers / sizes.
  *      dvae_grad_norm: total 2-norm of all gradients -> norm_out[0], and

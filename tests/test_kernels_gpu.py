@@ -489,6 +489,73 @@ def test_skinny_gemm(ops, B, N, K):
     assert rel_err(obuf[:, :N], base + a @ w) < 2e-6
 
 
+@pytest.mark.parametrize('T,B,H,chains', [(19, 32, 256, 2), (5, 70, 128, 2), (20, 256, 256, 1), (7, 3, 256, 2),
+                                          (4, 33, 512, 1), (1, 32, 256, 2)])
+def test_lstm_seq_fwd_whole_recurrence_in_one_launch(ops, T, B, H, chains):
+    """dvae_lstm_seq_fwd_f32 (weights in registers, hidden state handed between workgroups inside the
+    launch) against the fp64 recurrence: encoder-style chains (input projections, zero initial state, the
+    second one walking backwards) writing into column slices of one [T,B,chains*H] buffer."""
+    assert ops.lstm_seq_supported(chains, T, B, H)
+    D = chains
+    hseq = torch.zeros(T, B, D * H, device='cuda')
+    specs, refs = [], []
+    for d in range(D):
+        xproj = rnd(T, B, 4 * H, seed=90 + d)
+        w = rnd(4 * H, H, seed=92 + d, scale=0.08)
+        b_a, b_b = rnd(4 * H, seed=94 + d, scale=0.1), rnd(4 * H, seed=96 + d, scale=0.1)
+        h, c = torch.zeros(B, H, dtype=torch.float64), torch.zeros(B, H, dtype=torch.float64)
+        rg, rh, rc = [None] * T, [None] * T, [None] * T
+        for t in (range(T - 1, -1, -1) if d == 1 else range(T)):
+            pre = xproj[t] + b_a + b_b + h @ w.t()
+            i, f, g, o = pre.chunk(4, 1)
+            rg[t] = torch.cat([torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)], 1)
+            h, c = O.lstm_cell(xproj[t] + b_a + b_b, h, c, w)
+            rh[t], rc[t] = h, c
+        refs.append((torch.stack(rg), torch.stack(rh), torch.stack(rc)))
+        specs.append(dict(xproj=dev(xproj), w_rec=dev(w), b_a=dev(b_a), b_b=dev(b_b),
+                          gates=torch.empty(T, B, 4 * H, device='cuda'), hseq=hseq[:, :, d * H:(d + 1) * H],
+                          cseq=torch.empty(T, B, H, device='cuda'), reverse=(d == 1)))
+    ws = ops.lstm_seq_fwd(specs, T, B, H)
+    torch.cuda.synchronize()
+    assert int(ws[:1].view(torch.int32).item()) == 0, 'a wait inside the launch ran into its time bound'
+    for d in range(D):
+        rg, rh, rc = refs[d]
+        assert rel_err(specs[d]['gates'], rg) < 5e-6
+        assert rel_err(specs[d]['cseq'], rc) < 5e-6
+        assert rel_err(hseq[:, :, d * H:(d + 1) * H], rh) < 5e-6
+    # and twice in a row gives the same bits (counters and exchange buffers are re-initialised per launch)
+    first = hseq.clone()
+    ops.lstm_seq_fwd(specs, T, B, H)
+    assert torch.equal(first, hseq)
+
+
+@pytest.mark.parametrize('T,B,H', [(19, 32, 256), (6, 40, 128)])
+def test_lstm_seq_fwd_from_an_initial_state_without_input(ops, T, B, H):
+    """the decoder's form: no input projection, strided initial state, combined weights"""
+    w = rnd(4 * H, H, seed=101, scale=0.08)
+    b_a, b_b = rnd(4 * H, seed=102, scale=0.1), rnd(4 * H, seed=103, scale=0.1)
+    init = rnd(B, 2 * H, seed=104)                       # h0 | c0 side by side: row stride 2H
+    h, c = init[:, :H].clone(), init[:, H:].clone()
+    rh = []
+    for t in range(T):
+        h, c = O.lstm_cell((b_a + b_b).expand(B, -1), h, c, w)
+        rh.append(h)
+    dinit = dev(init)
+    spec = dict(w_rec=dev(w), b_a=dev(b_a), b_b=dev(b_b), h_init=dinit[:, :H], c_init=dinit[:, H:],
+                gates=torch.empty(T, B, 4 * H, device='cuda'), hseq=torch.empty(T, B, H, device='cuda'),
+                cseq=torch.empty(T, B, H, device='cuda'))
+    ws = ops.lstm_seq_fwd([spec], T, B, H)
+    assert int(ws[:1].view(torch.int32).item()) == 0
+    assert rel_err(spec['hseq'], torch.stack(rh)) < 5e-6
+    assert rel_err(spec['cseq'][-1], c) < 5e-6
+
+
+def test_lstm_seq_rejects_what_cannot_be_resident(ops):
+    assert not ops.lstm_seq_supported(2, 19, 256, 256)           # 512 workgroups
+    assert not ops.lstm_seq_supported(1, 19, 32, 32)             # hidden size without a kernel
+    assert ops.lstm_seq_supported(2, 19, 128, 256) and ops.lstm_seq_supported(1, 19, 256, 256)
+
+
 # ------------------------------------------------------------------ optimiser
 def test_grad_norm_clip_adam(ops):
     g = torch.Generator().manual_seed(80)

@@ -51,6 +51,18 @@ def main():
                               w_hh, bi, bh, gates[t], hseq[t], cseq[t])
     us = replay_time(fwd)
     print(f'forward : {us / T:6.2f} us per step ({T} dependent steps in one graph)', flush=True)
+    for Bs in (32, 64, 128, 256):
+        if not ops.lstm_seq_supported(1, T, Bs, H):
+            continue
+        spec = dict(xproj=xproj[:, :Bs].contiguous(), w_rec=w_hh, b_a=bi, b_b=bh, gates=gates[:, :Bs].contiguous(),
+                    hseq=hseq[:, :Bs].contiguous(), cseq=cseq[:, :Bs].contiguous())
+        us = replay_time(lambda: ops.lstm_seq_fwd([spec], T, Bs, H))
+        print(f'forward, whole recurrence in one launch, B={Bs:3d}: {us / T:6.2f} us per step', flush=True)
+        if Bs <= 128:
+            two = [spec, dict(spec, gates=torch.empty_like(spec['gates']), hseq=torch.empty_like(spec['hseq']),
+                              cseq=torch.empty_like(spec['cseq']), reverse=True)]
+            us = replay_time(lambda: ops.lstm_seq_fwd(two, T, Bs, H))
+            print(f'   two chains (both directions) in one launch, B={Bs:3d}: {us / T:6.2f} us per step', flush=True)
 
     w_t = w_hh.t().contiguous()
     dh = torch.randn(T, B, H, device=dev) * 0.01
