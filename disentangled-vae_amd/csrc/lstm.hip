@@ -370,18 +370,18 @@ extern "C" int dvae_skinny_gemm_nt_f32(const float* a, int64_t ld_a, const float
 // the K dimension in MFMA operand layout), keeps the cell state of its 32 x 8 elements in registers, and
 // per step needs only the group's previous hidden state [32 x H] from the other workgroups of its group.
 // That hand-off goes through global memory inside the launch:
-//   producer  four waves store the new 32 x 8 block of h write-through (agent-scope atomic stores: one
-//             256-byte run per wave instruction, whole 128-byte lines), each wave drains its stores
+//   producer  the new 32 x 8 block of h is collected in LDS and stored write-through (sc1) by one wave
+//             instruction of 16-byte stores (1 KB, whole 128-byte lines); that wave drains its stores
 //             (s_waitcnt vmcnt(0)) and one lane of it adds 1 to the group's arrival counter;
-//   consumer  one lane polls the counter with agent-scope loads until all 4*(H/8) arrivals of the step are
+//   consumer  one lane polls the counter with agent-scope loads until all H/8 arrivals of the step are
 //             in, the workgroup passes a barrier, and then every wave fetches its part of h with
-//             write-through-coherent (sc1) 16-byte loads only.
+//             L1-bypassing (sc1) 16-byte loads only.
 // Two buffers alternate: a workgroup can only write step t+1 after every workgroup of its group has
 // written step t, i.e. has finished reading step t-1.  Groups never wait for each other.  Workgroups of a
 // group are numbered eight apart so that they tend to share an XCD's L2 (speed only).  Every wait is
 // bounded: after LSTM_SEQ_TIMEOUT_TICKS without progress a workgroup raises the launch's timeout word
 // and leaves; the others see the word and leave too, so the grid always drains.  All workgroups of a
-// launch must be resident together: the host launches at most one per compute unit.
+// launch must be resident together: the host launches at most two per compute unit.
 // ------------------------------------------------------------------------------------------------
 #define SEQ_WAVES 8
 #define SEQ_MAX_CHAINS 2
@@ -420,9 +420,15 @@ __device__ __forceinline__ f32x4 load_x4_sc1(const float* p) {
   return v;
 }
 
+// 16-byte write-through store; the trailing nop keeps the data registers until the store has read them
+__device__ __forceinline__ void store_x4_sc1(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+
 template <int KW>      // K per wave = H / 8: 16, 32 or 64
-__global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_seq_fwd_kernel(LstmSeqArgs g) {
+__global__ void __launch_bounds__(64 * SEQ_WAVES, SEQ_WAVES / 2) lstm_seq_fwd_kernel(LstmSeqArgs g) {
   __shared__ float red[SEQ_WAVES * 32 * KS_RED_LD];
+  __shared__ __attribute__((aligned(16))) float hx[32 * 8];
   __shared__ int s_abort;
   constexpr int NQ = KW / 2;                 // MFMAs per wave and step; also units per lane half
   const int H = g.H, NS = H / 8;
@@ -495,7 +501,7 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_seq_fwd_kernel(LstmSeqArg
       }
     } else {
       if (threadIdx.x == 0) {
-        const unsigned target = 4u * (unsigned)NS * (unsigned)step;
+        const unsigned target = (unsigned)NS * (unsigned)step;
         const long long t0 = wall_clock64();
         bool ok = true;
         while (__hip_atomic_load((gu32_t*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -545,6 +551,7 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_seq_fwd_kernel(LstmSeqArg
     }
     ks_spill(red, acc, wave, lane);
     __syncthreads();
+    float ig_o = 0.f, fg_o = 0.f, gg_o = 0.f, og_o = 0.f, hn_o = 0.f;
     if (cell) {
       float pre[4];
 #pragma unroll
@@ -558,25 +565,31 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_seq_fwd_kernel(LstmSeqArg
       const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
       cstate = fg * cstate + ig * gg;
       const float hn = og * tanhf(cstate);
-      if (step + 1 < g.T) {
-        // hand the new state to the group: [slice][row][8], one float per thread = 256 B per wave instruction
-        float* dst = xch + (int64_t)(step & 1) * H * 32 + ((int64_t)slice * 32 + bl) * 8 + jj;
-        __hip_atomic_store((__attribute__((address_space(1))) float*)dst, bok ? hn : 0.f, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (bok) {
-        float* go = c.gates + ((int64_t)t * g.B + b) * 4 * H;
-        go[0 * H + j] = ig;
-        go[1 * H + j] = fg;
-        go[2 * H + j] = gg;
-        go[3 * H + j] = og;
-        c.cseq[((int64_t)t * g.B + b) * H + j] = cstate;
-        c.hseq[(int64_t)t * c.step_h + b * c.ld_h + j] = hn;
-      }
-      if (step + 1 < g.T) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
+      ig_o = ig; fg_o = fg; gg_o = gg; og_o = og; hn_o = hn;
+      hx[bl * 8 + jj] = bok ? hn : 0.f;
+    }
+    if (step + 1 < g.T) {
+      // the hand-off is the critical path.  The new 32 x 8 block of h goes to the group as ONE wave instruction
+      // of 16-byte write-through stores (1 KB, whole lines), then one lane signals for the workgroup: arrivals
+      // on one word are served one after the other, so there is one per workgroup and step.
+      __syncthreads();
+      if (wave == 0) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&hx[lane * 4]);
+        float* dst = xch + (int64_t)(step & 1) * H * 32 + (int64_t)slice * 256 + lane * 4;
+        store_x4_sc1(dst, v);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add((gu32_t*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+    }
+    // the step's own outputs behind it
+    if (bok) {
+      float* go = c.gates + ((int64_t)t * g.B + b) * 4 * H;
+      go[0 * H + j] = ig_o;
+      go[1 * H + j] = fg_o;
+      go[2 * H + j] = gg_o;
+      go[3 * H + j] = og_o;
+      c.cseq[((int64_t)t * g.B + b) * H + j] = cstate;
+      c.hseq[(int64_t)t * c.step_h + b * c.ld_h + j] = hn_o;
     }
     // (the next step's barrier behind the poll keeps `red` from being overwritten while it is read)
   }
@@ -590,8 +603,9 @@ extern "C" int64_t dvae_lstm_seq_ws_floats(int64_t nchains, int64_t B, int64_t H
 extern "C" int dvae_lstm_seq_supported(int64_t nchains, int64_t T, int64_t B, int64_t H) {
   if (nchains < 1 || nchains > SEQ_MAX_CHAINS || T < 1 || B < 1) return 0;
   if (H != 128 && H != 256 && H != 512) return 0;
-  // every workgroup must be resident at once: at most one per compute unit of the 256
-  return nchains * ceil_div64(B, 32) * (H / 8) <= 256;
+  // every workgroup must be resident at once: two of these 512-thread workgroups fit a compute unit
+  // (launch bounds: at most 128 registers per lane), and there are 256 compute units
+  return nchains * ceil_div64(B, 32) * (H / 8) <= 512;
 }
 
 extern "C" int dvae_lstm_seq_fwd_f32(int64_t nchains, const float* const* xproj, const float* const* w_rec,
@@ -602,7 +616,7 @@ extern "C" int dvae_lstm_seq_fwd_f32(int64_t nchains, const float* const* xproj,
                                      float* ws, dvae_stream_t stream) {
   DVAE_REQUIRE(dvae_lstm_seq_supported(nchains, T, B, H),
                "lstm_seq_fwd: unsupported shape (chains=%ld T=%ld B=%ld H=%ld): H must be 128, 256 or 512 and "
-               "chains*ceil(B/32)*(H/8) at most 256", (long)nchains, (long)T, (long)B, (long)H);
+               "chains*ceil(B/32)*(H/8) at most 512", (long)nchains, (long)T, (long)B, (long)H);
   DVAE_REQUIRE(ws != nullptr && (((uintptr_t)ws) & 255) == 0, "lstm_seq_fwd: workspace must be 256-byte aligned");
   LstmSeqArgs g;
   g.nchains = (int)nchains; g.T = (int)T; g.B = B; g.H = (int)H;
@@ -637,5 +651,286 @@ extern "C" int dvae_lstm_seq_fwd_f32(int64_t nchains, const float* const* xproj,
   else if (H == 256) DVAE_LAUNCH((lstm_seq_fwd_kernel<32>), dim3(nblocks), dim3(64 * SEQ_WAVES), 0, ST(stream), g);
   else DVAE_LAUNCH((lstm_seq_fwd_kernel<64>), dim3(nblocks), dim3(64 * SEQ_WAVES), 0, ST(stream), g);
   DVAE_LAUNCH_CHECK("lstm_seq_fwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Whole recurrence in ONE launch (backward through time).
+//
+// Same partition as the forward launch: a group of 32 batch rows is served by H/8 workgroups, and a
+// workgroup owns eight hidden units: their gate gradients of every step, their carried cell gradient
+// (in a register) and the 32 rows of the recurrent weights that belong to their gates (in registers, as
+// MFMA B operands).  The hidden-state gradient of the previous step is dh += dG * W, a sum over ALL gate
+// columns, so here the workgroups exchange partial products instead of states: after the pointwise
+// step a workgroup multiplies its 32 x 32 block of dG (through LDS) with its 32 x H weight rows and
+// writes the 32 x H partial, ordered by destination workgroup, to the exchange area; the owner of a
+// hidden-unit slice adds the H/8 partials of its slice in workgroup order (fixed order: run-to-run
+// identical bits) to the gradient that arrives from outside.  Arrival counters, the two alternating
+// exchange buffers, the bounded waits and the residency requirement are those of the forward launch.
+// ------------------------------------------------------------------------------------------------
+#define SEQ_A_LD 36
+
+struct LstmSeqBwdChain {
+  const float* w_rec;        // [4H][H]
+  const float* gates;        // [T][B][4H] activated gates of the forward pass
+  const float* cseq;         // [T][B][H]
+  const float* c_init; int64_t ld_cinit;     // cell state before the chain's first step, or nullptr (zeros)
+  const float* dh_ext; int64_t ld_dh; int64_t step_dh;   // gradient reaching h of step t from outside the chain
+  float* dgates;             // [T][B][4H] gradient wrt the gate pre-activations, out
+  float* dh_init; int64_t ld_dhinit;         // gradient wrt the hidden state before the first step, or nullptr
+  float* dc_init; int64_t ld_dcinit;         // gradient wrt the cell state before the first step (with dh_init)
+  int reverse;               // the forward pass walked t = T-1 .. 0
+};
+
+struct LstmSeqBwdArgs {
+  LstmSeqBwdChain ch[SEQ_MAX_CHAINS];
+  int nchains;
+  int T;
+  int64_t B;
+  int groups_per_chain;
+  int accumulate_dh_init;    // dh_init += instead of =
+  unsigned* sync;
+  float* xch;                // [group][2][writer H/8][destination H/8][32 rows][8]
+};
+
+typedef __attribute__((address_space(1))) float gf32_t;
+
+// thread 0 waits until the group's counter has reached `target`; returns false for the whole workgroup
+// when the wait ran into its bound or another workgroup raised the timeout word
+__device__ __forceinline__ bool seq_wait(unsigned* cnt, unsigned* tmo, unsigned target, int* s_abort) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    bool ok = true;
+    while (__hip_atomic_load((gu32_t*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > LSTM_SEQ_TIMEOUT_TICKS ||
+          __hip_atomic_load((gu32_t*)tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        ok = false;
+        break;
+      }
+    }
+    if (!ok) {
+      __hip_atomic_store((gu32_t*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_abort = 1;
+    }
+  }
+  __syncthreads();
+  return *s_abort == 0;
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#define SEQ_AUX_SC1 16      // cache-policy bits of a raw buffer access: write-through store / L1-bypassing load
+
+template <int HH>      // hidden size: 128, 256 or 512
+__global__ void __launch_bounds__(64 * SEQ_WAVES, SEQ_WAVES / 2) lstm_seq_bwd_kernel(LstmSeqBwdArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[32 * SEQ_A_LD];                 // dG block, MFMA A operand
+  __shared__ __attribute__((aligned(16))) float Ts[SEQ_WAVES * 32 * SEQ_A_LD];     // per wave: product tile on its way out
+  __shared__ __attribute__((aligned(16))) float red[SEQ_WAVES * 32 * 8];           // per wave: partial sums on their way in
+  __shared__ int s_abort;
+  constexpr int H = HH, NS = HH / 8;
+  constexpr int NTILE = HH / 32;                            // 32-column tiles of the partial product
+  constexpr int NT = (NTILE + SEQ_WAVES - 1) / SEQ_WAVES;   // tiles per wave
+  constexpr int NW = NS / SEQ_WAVES;                        // writers whose partials one wave fetches
+  const int ngroups = g.nchains * g.groups_per_chain;
+  const int per8 = 8 * NS;
+  const int group = (int)(blockIdx.x % 8) + 8 * (int)(blockIdx.x / per8);
+  const int slice = (int)(blockIdx.x % per8) / 8;
+  if (group >= ngroups) return;
+  const LstmSeqBwdChain& c = g.ch[group / g.groups_per_chain];
+  const int64_t b0 = (int64_t)(group % g.groups_per_chain) * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  unsigned* const tmo = g.sync;
+  unsigned* const cnt = g.sync + SEQ_CNT_STRIDE * (1 + group);
+  // the group's exchange area [2][writer][destination slice][32 rows][8], addressed through a buffer
+  // descriptor: 16-byte write-through stores and L1-bypassing loads that the compiler counts itself
+  constexpr unsigned XBUF = (unsigned)NS * 32u * H;         // floats per buffer
+  const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(g.xch + (int64_t)group * 2 * XBUF, 0, 2 * XBUF * 4, 0x00020000);
+  if (threadIdx.x == 0) s_abort = 0;
+
+  // weight rows of this workgroup's 32 gate columns: local k = 8*gate + unit; lane half hh feeds k = 16*hh + i
+  // to MFMA i, as row (k/8)*H + 8*slice + k%8 of w_rec and column 32*tile + l31
+  float wreg[NT][16];
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt) {
+    const int tile = wave + SEQ_WAVES * tt;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = 16 * hh + i;
+      wreg[tt][i] = tile < NTILE ? c.w_rec[((int64_t)(k >> 3) * H + slice * 8 + (k & 7)) * H + tile * 32 + l31] : 0.f;
+    }
+  }
+  const int bl = threadIdx.x >> 3, jj = threadIdx.x & 7;
+  const bool cell = threadIdx.x < 256;
+  const int64_t b = b0 + bl, j = (int64_t)slice * 8 + jj;
+  const bool bok = cell && b < g.B;
+  const int xrow = lane >> 1, xhalf = lane & 1;              // exchange role: 16 bytes of row xrow
+  float dcarry = 0.f;
+  __syncthreads();
+
+  // sum over all writers of this slice's 32 x 8 block in `buf`: every wave fetches NW writers' blocks
+  // (one 1-KB block per wave instruction), adds them in writer order and leaves its sum in `red`
+  auto gather = [&](int buf) {
+    u32x4 v[NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const unsigned w = (unsigned)(wave * NW + q);
+      const unsigned off = ((unsigned)buf * XBUF + w * 32u * H + (unsigned)slice * 256u + (unsigned)lane * 4u) * 4u;
+      v[q] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, SEQ_AUX_SC1);
+    }
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NW; ++q) s += __builtin_bit_cast(f32x4, v[q]);
+    *reinterpret_cast<f32x4*>(&red[(wave * 32 + xrow) * 8 + xhalf * 4]) = s;
+    __syncthreads();
+  };
+  auto gathered = [&]() {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < SEQ_WAVES; ++w) s += red[(w * 32 + bl) * 8 + jj];
+    return s;
+  };
+
+  for (int step = 0; step < g.T; ++step) {
+    const int t = c.reverse ? step : g.T - 1 - step;
+    const bool has_prev = step + 1 < g.T;
+    const int tp = c.reverse ? t + 1 : t - 1;
+    // everything the pointwise step needs besides the exchanged sum: requested before the wait
+    float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cv = 0.f, cpv = 0.f, dhv = 0.f;
+    if (bok) {
+      const float* gt = c.gates + ((int64_t)t * g.B + b) * 4 * H + j;
+      ig = gt[0]; fg = gt[H]; gg = gt[2 * H]; og = gt[3 * H];
+      cv = c.cseq[((int64_t)t * g.B + b) * H + j];
+      if (has_prev) cpv = c.cseq[((int64_t)tp * g.B + b) * H + j];
+      else if (c.c_init) cpv = c.c_init[b * c.ld_cinit + j];
+      dhv = c.dh_ext[(int64_t)t * c.step_dh + b * c.ld_dh + j];
+    }
+    if (step > 0) {
+      if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)step, &s_abort)) return;
+      gather((step - 1) & 1);
+      if (cell) dhv += gathered();
+    }
+    float dg0 = 0.f, dg1 = 0.f, dg2 = 0.f, dg3 = 0.f;
+    if (cell) {
+      const float tc = tanhf(cv);
+      const float dct = dcarry + dhv * og * (1.f - tc * tc);
+      dg0 = dct * gg * ig * (1.f - ig);
+      dg1 = dct * cpv * fg * (1.f - fg);
+      dg2 = dct * ig * (1.f - gg * gg);
+      dg3 = dhv * tc * og * (1.f - og);
+      dcarry = dct * fg;
+      if (!bok) dg0 = dg1 = dg2 = dg3 = 0.f;
+      As[bl * SEQ_A_LD + 0 * 8 + jj] = dg0;
+      As[bl * SEQ_A_LD + 1 * 8 + jj] = dg1;
+      As[bl * SEQ_A_LD + 2 * 8 + jj] = dg2;
+      As[bl * SEQ_A_LD + 3 * 8 + jj] = dg3;
+    }
+    const bool product = has_prev || c.dh_init != nullptr;
+    if (product) {
+      __syncthreads();
+      f32x4 av[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const f32x4*>(&As[l31 * SEQ_A_LD + 16 * hh + 4 * q]);
+      float* const tsw = Ts + wave * 32 * SEQ_A_LD;
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const int tile = wave + SEQ_WAVES * tt;
+        if (tile < NTILE) {
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][0], wreg[tt][4 * q + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][1], wreg[tt][4 * q + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][2], wreg[tt][4 * q + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][3], wreg[tt][4 * q + 3], acc, 0, 0, 0);
+          }
+          // through the wave's own LDS tile into destination order: columns 8q..8q+7 of the tile belong to
+          // destination slice 4*tile + q, whose [32 rows][8] block is 1 KB = one 16-byte store per lane
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tsw[((r & 3) + 8 * (r >> 2) + 4 * hh) * SEQ_A_LD + l31] = acc[r];
+          // (same wave wrote and reads: LDS operations of a wave complete in order)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&tsw[xrow * SEQ_A_LD + q * 8 + xhalf * 4]);
+            const unsigned off = ((unsigned)(step & 1) * XBUF + (unsigned)slice * 32u * H +
+                                  (unsigned)(tile * 4 + q) * 256u + (unsigned)lane * 4u) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xrsrc, off, 0, SEQ_AUX_SC1);
+          }
+        }
+      }
+      // one arrival per workgroup (arrivals on one word are served one after the other): every wave drains
+      // its stores, the workgroup meets, one lane signals
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add((gu32_t*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the step's own output goes out behind the hand-off
+    if (bok) {
+      float* dg = c.dgates + ((int64_t)t * g.B + b) * 4 * H + j;
+      dg[0] = dg0; dg[H] = dg1; dg[2 * H] = dg2; dg[3 * H] = dg3;
+    }
+    // (As and red are rewritten only behind the next step's wait, whose barrier every wave reaches after its reads)
+  }
+  if (c.dh_init != nullptr) {
+    if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)g.T, &s_abort)) return;
+    gather((g.T - 1) & 1);
+    if (bok) {
+      const float s = gathered();
+      float* dst = c.dh_init + b * c.ld_dhinit + j;
+      *dst = g.accumulate_dh_init ? *dst + s : s;
+      if (c.dc_init) c.dc_init[b * c.ld_dcinit + j] = dcarry;
+    }
+  }
+}
+
+extern "C" int64_t dvae_lstm_seq_bwd_ws_floats(int64_t nchains, int64_t B, int64_t H) {
+  const int64_t groups = nchains * ceil_div64(B, 32);
+  return SEQ_CNT_STRIDE * (1 + groups) + groups * 2 * (H / 8) * 32 * H;
+}
+
+extern "C" int dvae_lstm_seq_bwd_f32(int64_t nchains, const float* const* w_rec, const float* const* gates,
+                                     const float* const* cseq, const float* const* c_init, int64_t ld_cinit,
+                                     const float* const* dh_ext, int64_t ld_dh, int64_t step_dh,
+                                     float* const* dgates, float* const* dh_init, int64_t ld_dhinit,
+                                     float* const* dc_init, int64_t ld_dcinit, int accumulate_dh_init,
+                                     const int* reverse, int64_t T, int64_t B, int64_t H, float* ws,
+                                     dvae_stream_t stream) {
+  DVAE_REQUIRE(dvae_lstm_seq_supported(nchains, T, B, H),
+               "lstm_seq_bwd: unsupported shape (chains=%ld T=%ld B=%ld H=%ld): H must be 128, 256 or 512 and "
+               "chains*ceil(B/32)*(H/8) at most 512", (long)nchains, (long)T, (long)B, (long)H);
+  DVAE_REQUIRE(ws != nullptr && (((uintptr_t)ws) & 255) == 0, "lstm_seq_bwd: workspace must be 256-byte aligned");
+  DVAE_REQUIRE(w_rec && gates && cseq && dh_ext && dgates, "lstm_seq_bwd: null argument");
+  LstmSeqBwdArgs g;
+  g.nchains = (int)nchains; g.T = (int)T; g.B = B;
+  g.groups_per_chain = (int)ceil_div64(B, 32);
+  g.accumulate_dh_init = accumulate_dh_init;
+  for (int i = 0; i < nchains; ++i) {
+    LstmSeqBwdChain& c = g.ch[i];
+    c.w_rec = w_rec[i]; c.gates = gates[i]; c.cseq = cseq[i];
+    c.c_init = c_init ? c_init[i] : nullptr; c.ld_cinit = ld_cinit;
+    c.dh_ext = dh_ext[i]; c.ld_dh = ld_dh; c.step_dh = step_dh;
+    c.dgates = dgates[i];
+    c.dh_init = dh_init ? dh_init[i] : nullptr; c.ld_dhinit = ld_dhinit;
+    c.dc_init = dc_init ? dc_init[i] : nullptr; c.ld_dcinit = ld_dcinit;
+    c.reverse = reverse ? reverse[i] : 0;
+    DVAE_REQUIRE(c.w_rec && c.gates && c.cseq && c.dh_ext && c.dgates, "lstm_seq_bwd: null argument (chain %d)", i);
+    DVAE_REQUIRE(c.dc_init == nullptr || c.dh_init != nullptr, "lstm_seq_bwd: dc_init comes with dh_init");
+  }
+  const int groups = g.nchains * g.groups_per_chain;
+  g.sync = (unsigned*)ws;
+  g.xch = ws + SEQ_CNT_STRIDE * (1 + groups);
+  if (hipMemsetAsync(ws, 0, sizeof(unsigned) * SEQ_CNT_STRIDE * (1 + groups), ST(stream)) != hipSuccess) {
+    dvae_set_error("lstm_seq_bwd: clearing the counters failed: %s", hipGetErrorString(hipGetLastError()));
+    return -EIO;
+  }
+  const int NS = (int)(H / 8);
+  const unsigned nblocks = (unsigned)(8 * NS * ((groups + 7) / 8));
+  DVAE_WORK(2.0 * (double)nchains * T * B * 4 * H * H, DVAE_UNIT_FLOP);
+  if (H == 128) DVAE_LAUNCH((lstm_seq_bwd_kernel<128>), dim3(nblocks), dim3(64 * SEQ_WAVES), 0, ST(stream), g);
+  else if (H == 256) DVAE_LAUNCH((lstm_seq_bwd_kernel<256>), dim3(nblocks), dim3(64 * SEQ_WAVES), 0, ST(stream), g);
+  else DVAE_LAUNCH((lstm_seq_bwd_kernel<512>), dim3(nblocks), dim3(64 * SEQ_WAVES), 0, ST(stream), g);
+  DVAE_LAUNCH_CHECK("lstm_seq_bwd");
   return 0;
 }

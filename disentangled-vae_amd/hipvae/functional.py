@@ -430,9 +430,15 @@ class LSTMEncoder(torch.autograd.Function):
             dgs = [_empty(T, B, 4 * H, like=dfinal) for _ in range(D)]
             dcs = [[_empty(B, H, like=dfinal), _empty(B, H, like=dfinal)] for _ in range(D)]
             w_hhs = [weights[(l * D + d) * 4 + 1].contiguous() for d in range(D)]
-            w_hh_t = [w.t().contiguous() for w in w_hhs]      # [H, 4H]: k-contiguous rows for dh = dG * W_hh
-            with _TwoLanes(dfinal, D == 2) as lanes:
-                for i in range(T - 1, -1, -1):                    # walk the recurrences backwards
+            seq = USE_SEQ_KERNELS and ops.lstm_seq_supported(D, T, B, H)
+            if seq:
+                # both directions' chains in one launch, recurrent weights in registers
+                ops.lstm_seq_bwd([dict(w_rec=w_hhs[d], gates=gates[d], cseq=cseq[d],
+                                       dh_ext=dh[:, :, d * H:(d + 1) * H], dgates=dgs[d], reverse=(d == 1))
+                                  for d in range(D)], T, B, H)
+            w_hh_t = [] if seq else [w.t().contiguous() for w in w_hhs]   # [H, 4H]: k-contiguous rows for dh = dG * W_hh
+            with _TwoLanes(dfinal, D == 2 and not seq) as lanes:
+                for i in (() if seq else range(T - 1, -1, -1)):   # walk the recurrences backwards
                     for d in range(D):
                         t = T - 1 - i if d == 1 else i
                         tp = None if i == 0 else (t + 1 if d == 1 else t - 1)
@@ -547,13 +553,20 @@ class LSTMDecoder(torch.autograd.Function):
         w_hh_t = [weights[4 * l + 1].t().contiguous() for l in range(L)]
         w_comb_t = (w_ih_t[0] + w_hh_t[0]) if (L == 1 and T > 1) else None
         fused = w_comb_t is not None      # single layer: one launch per step (product + next pointwise)
-        for t in range(T - 1, -1, -1):
+        seq = fused and USE_SEQ_KERNELS and ops.lstm_seq_supported(1, T - 1, B, H)
+        if seq:
+            # steps T-1 .. 1 in one launch (W_ih + W_hh in registers); it leaves dL/dh_0 and dL/dc_0 for step 0
+            ops.lstm_seq_bwd([dict(w_rec=weights[0] + weights[1], gates=gates[0, 1:], cseq=cs[0, 1:], c_init=cs[0, 0],
+                                   dh_ext=dhs[0, 1:], dgates=dg[0, 1:], dh_init=dhs[0, 0], dc_init=dcbuf[0][1])],
+                             T - 1, B, H, accumulate_dh_init=True)
+            ops.lstm_step_bwd_pointwise(dhs[0, 0], dcbuf[0][1], gates[0, 0], c0[:, :H], cs[0, 0], dg[0, 0], dc0[:, :H])
+        for t in ((0,) if seq else range(T - 1, -1, -1)):
             for l in range(L - 1, -1, -1):
                 w_ih, w_hh = w_ih_t[l], w_hh_t[l]
                 c_prev = c0[:, l * H:(l + 1) * H] if t == 0 else cs[l, t - 1]
                 dc_in = None if t == T - 1 else dcbuf[l][(t + 1) & 1]
                 dc_out = dc0[:, l * H:(l + 1) * H] if t == 0 else dcbuf[l][t & 1]
-                if not fused or t == T - 1:
+                if (not fused or t == T - 1) and not seq:
                     ops.lstm_step_bwd_pointwise(dhs[l, t], dc_in, gates[l, t], c_prev, cs[l, t], dg[l, t], dc_out)
                 if fused and t > 0:
                     # dh_{t-1} += dG_t (W_ih + W_hh), then straight through the cell of step t-1

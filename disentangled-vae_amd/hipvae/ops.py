@@ -653,6 +653,41 @@ def lstm_seq_fwd(chains, T: int, B: int, H: int):
     return ws
 
 
+def lstm_seq_bwd(chains, T: int, B: int, H: int, accumulate_dh_init: bool = False):
+    """Backpropagation through time of up to two independent chains in one launch.  Each chain is a dict with
+    w_rec [4H,H], gates [T,B,4H], cseq [T,B,H], dh_ext (a [T,B,>=H] view), dgates [T,B,4H] (out), and optionally
+    c_init [B,H] view, dh_init / dc_init [B,H] views (out), reverse."""
+    n = len(chains)
+    get = lambda k: [c.get(k) for c in chains]
+    for c in chains:
+        _chk2(c['w_rec'], c['gates'], c['cseq'], c.get('c_init'), c['dh_ext'], c['dgates'], c.get('dh_init'),
+              c.get('dc_init'))
+        assert c['w_rec'].is_contiguous() and c['gates'].is_contiguous() and c['cseq'].is_contiguous()
+        assert c['dgates'].is_contiguous() and c['dgates'].shape == (T, B, 4 * H)
+        assert c['dh_ext'].shape[:2] == (T, B) and c['dh_ext'].stride(2) == 1
+    d0 = chains[0]['dh_ext']
+    ld_dh, step_dh = d0.stride(1), d0.stride(0)
+    assert all(c['dh_ext'].stride(1) == ld_dh and c['dh_ext'].stride(0) == step_dh for c in chains)
+
+    def common_ld(k):
+        ts = get(k)
+        assert all((t is None) == (ts[0] is None) for t in ts)
+        if ts[0] is None:
+            return 0
+        assert all(t.stride(1) == 1 and t.stride(0) == ts[0].stride(0) for t in ts)
+        return ts[0].stride(0)
+
+    ld_ci, ld_dhi, ld_dci = common_ld('c_init'), common_ld('dh_init'), common_ld('dc_init')
+    ws = workspace(lib.dvae_lstm_seq_bwd_ws_floats(n, B, H), chains[0]['w_rec'].device, 'lstm_seq')
+    rev = (ctypes.c_int * n)(*[int(bool(c.get('reverse', False))) for c in chains])
+    opt = lambda k: None if all(v is None for v in get(k)) else _ptr_array(get(k))
+    check(lib.dvae_lstm_seq_bwd_f32(n, _ptr_array(get('w_rec')), _ptr_array(get('gates')), _ptr_array(get('cseq')),
+                                    opt('c_init'), ld_ci, _ptr_array(get('dh_ext')), ld_dh, step_dh,
+                                    _ptr_array(get('dgates')), opt('dh_init'), ld_dhi, opt('dc_init'), ld_dci,
+                                    int(accumulate_dh_init), rev, T, B, H, _p(ws), _stream()), 'lstm_seq_bwd')
+    return ws
+
+
 # ---------------------------------------------------------------------------- optimiser
 class TensorTable:
     """Host-side pointer/size arrays for the multi-tensor kernels, rebuilt only when pointers move."""

@@ -341,7 +341,7 @@ int dvae_skinny_gemm_nt_f32(const float* a, int64_t ld_a, const float* wt, int64
  *      hseq + t*step_h + b*ld_h.  The recurrent weights stay in registers for all T steps: a group of 32
  *      batch rows is served by H/8 workgroups that exchange the hidden state through ws inside the launch.
  *      All workgroups must be resident together, so dvae_lstm_seq_supported() admits H in {128, 256, 512}
- *      and nchains*ceil(B/32)*(H/8) <= 256 only; otherwise -EINVAL (use the per-step calls).
+ *      and nchains*ceil(B/32)*(H/8) <= 512 only; otherwise -EINVAL (use the per-step calls).
  *      ws: dvae_lstm_seq_ws_floats(nchains, B, H) floats, 256-byte aligned; ws[0] (read as unsigned) is
  *      non-zero after the launch if a wait inside it ran into its 40 ms bound (outputs are then invalid).
  *      Not to be run concurrently with another launch of itself unless both fit the chip together. */
@@ -352,6 +352,28 @@ int dvae_lstm_seq_fwd_f32(int64_t nchains, const float* const* xproj, const floa
                           int64_t ld_hinit, const float* const* c_init, int64_t ld_cinit, float* const* gates,
                           float* const* hseq, int64_t ld_h, int64_t step_h, float* const* cseq, const int* reverse,
                           int64_t T, int64_t B, int64_t H, float* ws, dvae_stream_t stream);
+
+/* ---- backpropagation through time of the same recurrences in ONE launch (autograd of nn.LSTM at
+ *      models/encoders.py:161 and of the decoder loop, models/decoders.py:129-132,264-267).  Same partition,
+ *      residency rule (dvae_lstm_seq_supported) and chains as the forward call; steps are walked against
+ *      the forward order.  Per chain and step t:
+ *        dh  = dh_ext[t] + dG_{next} * w_rec      (next: the step walked just before; none for the first)
+ *        dc  = dc_{next} * f_{next} + dh * o * (1 - tanh^2 c_t)
+ *        dG_t = [dc g i(1-i), dc c_{prev} f(1-f), dc i (1-g^2), dh tanh(c_t) o(1-o)]   -> dgates [T][B][4H]
+ *      with c_prev the cell state of the chronologically previous step (c_init rows, stride ld_cinit, or
+ *      zeros before the chain's first step).  dh_ext: h-gradient arriving from outside the chain, step t at
+ *      dh_ext + t*step_dh + b*ld_dh.  dh_init (optional, NULL array or entry): receives (or, with
+ *      accumulate_dh_init, is increased by) the gradient wrt the hidden state before the chain's first step,
+ *      dc_init the one wrt the cell state.  The partial products of the workgroups of a row group are added
+ *      in a fixed order: results are bit-identical from run to run.
+ *      ws: dvae_lstm_seq_bwd_ws_floats(nchains, B, H) floats, 256-byte aligned; ws[0] as in the forward call. */
+int64_t dvae_lstm_seq_bwd_ws_floats(int64_t nchains, int64_t B, int64_t H);
+int dvae_lstm_seq_bwd_f32(int64_t nchains, const float* const* w_rec, const float* const* gates,
+                          const float* const* cseq, const float* const* c_init, int64_t ld_cinit,
+                          const float* const* dh_ext, int64_t ld_dh, int64_t step_dh, float* const* dgates,
+                          float* const* dh_init, int64_t ld_dhinit, float* const* dc_init, int64_t ld_dcinit,
+                          int accumulate_dh_init, const int* reverse, int64_t T, int64_t B, int64_t H, float* ws,
+                          dvae_stream_t stream);
 
 /* ---- optimiser (torch.optim.Adam with L2 weight decay and nn.utils.clip_grad_norm_ as called at
  *      training/trainer.py:56-61,198-204).  Host arrays of n device pointers / sizes.

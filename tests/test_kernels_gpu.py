@@ -490,7 +490,7 @@ def test_skinny_gemm(ops, B, N, K):
 
 
 @pytest.mark.parametrize('T,B,H,chains', [(19, 32, 256, 2), (5, 70, 128, 2), (20, 256, 256, 1), (7, 3, 256, 2),
-                                          (4, 33, 512, 1), (1, 32, 256, 2)])
+                                          (4, 33, 512, 1), (1, 32, 256, 2), (6, 256, 256, 2), (3, 100, 512, 2)])
 def test_lstm_seq_fwd_whole_recurrence_in_one_launch(ops, T, B, H, chains):
     """dvae_lstm_seq_fwd_f32 (weights in registers, hidden state handed between workgroups inside the
     launch) against the fp64 recurrence: encoder-style chains (input projections, zero initial state, the
@@ -550,10 +550,75 @@ def test_lstm_seq_fwd_from_an_initial_state_without_input(ops, T, B, H):
     assert rel_err(spec['cseq'][-1], c) < 5e-6
 
 
+def _lstm_chain_autograd(T, B, H, reverse, with_init, seed):
+    """fp64 autograd of one chain: returns the kernel's inputs (activated gates, cell states, dh_ext) and the
+    reference gradients wrt gate pre-activations and the initial state"""
+    xproj = rnd(T, B, 4 * H, seed=seed).requires_grad_(True)
+    w = rnd(4 * H, H, seed=seed + 1, scale=0.08)
+    ext = rnd(T, B, H, seed=seed + 2)
+    h = rnd(B, H, seed=seed + 3).requires_grad_(True) if with_init else torch.zeros(B, H, dtype=torch.float64)
+    c = rnd(B, H, seed=seed + 4).requires_grad_(True) if with_init else torch.zeros(B, H, dtype=torch.float64)
+    h_init, c_init = h, c
+    gates, cs, loss = [None] * T, [None] * T, 0.0
+    for t in (range(T - 1, -1, -1) if reverse else range(T)):
+        pre = xproj[t] + h @ w.t()
+        i, f, g, o = pre.chunk(4, 1)
+        i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+        c = f * c + i * g
+        h = o * torch.tanh(c)
+        gates[t], cs[t] = torch.cat([i, f, g, o], 1).detach(), c.detach()
+        loss = loss + (h * ext[t]).sum()
+    loss.backward()
+    return dict(w=w, ext=ext, gates=torch.stack(gates), cs=torch.stack(cs), dgates=xproj.grad,
+                h_init=h_init, c_init=c_init)
+
+
+@pytest.mark.parametrize('T,B,H,chains', [(19, 32, 256, 2), (5, 70, 128, 2), (20, 256, 256, 1), (7, 3, 256, 2),
+                                          (4, 33, 512, 1), (1, 32, 256, 2), (6, 256, 256, 2), (3, 100, 512, 2)])
+def test_lstm_seq_bwd_whole_recurrence_in_one_launch(ops, T, B, H, chains):
+    """dvae_lstm_seq_bwd_f32 against fp64 autograd: encoder-style chains from a zero state, the second one
+    reversed, the outside gradient read from column slices of one [T,B,chains*H] buffer."""
+    D = chains
+    refs = [_lstm_chain_autograd(T, B, H, d == 1, False, 200 + 10 * d) for d in range(D)]
+    dh = torch.zeros(T, B, D * H, device='cuda')
+    specs = []
+    for d, r in enumerate(refs):
+        dh[:, :, d * H:(d + 1) * H] = dev(r['ext'])
+        specs.append(dict(w_rec=dev(r['w']), gates=dev(r['gates']), cseq=dev(r['cs']),
+                          dh_ext=dh[:, :, d * H:(d + 1) * H], dgates=torch.empty(T, B, 4 * H, device='cuda'),
+                          reverse=(d == 1)))
+    ws = ops.lstm_seq_bwd(specs, T, B, H)
+    torch.cuda.synchronize()
+    assert int(ws[:1].view(torch.int32).item()) == 0, 'a wait inside the launch ran into its time bound'
+    for d, r in enumerate(refs):
+        assert rel_err(specs[d]['dgates'], r['dgates']) < 1e-5
+    first = [s['dgates'].clone() for s in specs]
+    ops.lstm_seq_bwd(specs, T, B, H)
+    assert all(torch.equal(a, s['dgates']) for a, s in zip(first, specs))
+
+
+@pytest.mark.parametrize('T,B,H', [(19, 32, 256), (6, 40, 128), (3, 256, 256)])
+def test_lstm_seq_bwd_hands_on_the_initial_state_gradients(ops, T, B, H):
+    """the decoder's form: an initial state whose gradients are wanted, dh_init accumulated onto what is there"""
+    r = _lstm_chain_autograd(T, B, H, False, True, 300)
+    base = rnd(B, H, seed=310)
+    dh_init = dev(base)
+    dc_init = torch.empty(B, 2 * H, device='cuda')[:, H:]          # strided output
+    spec = dict(w_rec=dev(r['w']), gates=dev(r['gates']), cseq=dev(r['cs']), c_init=dev(r['c_init'].detach()),
+                dh_ext=dev(r['ext']), dgates=torch.empty(T, B, 4 * H, device='cuda'), dh_init=dh_init, dc_init=dc_init)
+    ws = ops.lstm_seq_bwd([spec], T, B, H, accumulate_dh_init=True)
+    assert int(ws[:1].view(torch.int32).item()) == 0
+    assert rel_err(spec['dgates'], r['dgates']) < 1e-5
+    assert rel_err(dh_init, base + r['h_init'].grad) < 1e-5
+    assert rel_err(dc_init, r['c_init'].grad) < 1e-5
+    ops.lstm_seq_bwd([spec], T, B, H, accumulate_dh_init=False)
+    assert rel_err(dh_init, r['h_init'].grad) < 1e-5
+
+
 def test_lstm_seq_rejects_what_cannot_be_resident(ops):
-    assert not ops.lstm_seq_supported(2, 19, 256, 256)           # 512 workgroups
+    assert not ops.lstm_seq_supported(2, 19, 512, 256)           # 1024 workgroups
     assert not ops.lstm_seq_supported(1, 19, 32, 32)             # hidden size without a kernel
-    assert ops.lstm_seq_supported(2, 19, 128, 256) and ops.lstm_seq_supported(1, 19, 256, 256)
+    assert ops.lstm_seq_supported(2, 19, 256, 256) and ops.lstm_seq_supported(1, 19, 256, 512)
 
 
 # ------------------------------------------------------------------ optimiser

@@ -58,7 +58,7 @@ def main():
                     hseq=hseq[:, :Bs].contiguous(), cseq=cseq[:, :Bs].contiguous())
         us = replay_time(lambda: ops.lstm_seq_fwd([spec], T, Bs, H))
         print(f'forward, whole recurrence in one launch, B={Bs:3d}: {us / T:6.2f} us per step', flush=True)
-        if Bs <= 128:
+        if ops.lstm_seq_supported(2, T, Bs, H):
             two = [spec, dict(spec, gates=torch.empty_like(spec['gates']), hseq=torch.empty_like(spec['hseq']),
                               cseq=torch.empty_like(spec['cseq']), reverse=True)]
             us = replay_time(lambda: ops.lstm_seq_fwd(two, T, Bs, H))
@@ -76,6 +76,18 @@ def main():
                               cseq[i - 1], dgs[i - 1], dc[(i - 1) & 1])
     us = replay_time(bwd)
     print(f'backward: {us / T:6.2f} us per step', flush=True)
+
+    for Bs in (32, 64, 128, 256):
+        if not ops.lstm_seq_supported(1, T, Bs, H):
+            continue
+        spec = dict(w_rec=w_hh, gates=gates[:, :Bs].contiguous(), cseq=cseq[:, :Bs].contiguous(),
+                    dh_ext=dh[:, :Bs].contiguous(), dgates=dgs[:, :Bs].contiguous())
+        us = replay_time(lambda: ops.lstm_seq_bwd([spec], T, Bs, H))
+        print(f'backward, whole recurrence in one launch, B={Bs:3d}: {us / T:6.2f} us per step', flush=True)
+        if ops.lstm_seq_supported(2, T, Bs, H):
+            two = [spec, dict(spec, dgates=torch.empty_like(spec['dgates']), reverse=True)]
+            us = replay_time(lambda: ops.lstm_seq_bwd(two, T, Bs, H))
+            print(f'   two chains (both directions) in one launch, B={Bs:3d}: {us / T:6.2f} us per step', flush=True)
 
     # for scale: the same number of empty-ish dependent launches (a 1-block fill kernel)
     z = torch.zeros(64, device=dev)
