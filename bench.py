@@ -207,6 +207,7 @@ def main():
     ap.add_argument('--mode', default='train', choices=['train', 'infer'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-table', action='store_true')
+    ap.add_argument('--kernel-rows', type=int, default=16, help='rows of the per-kernel table in the result line')
     ap.add_argument('--bucket-mb', type=float, default=16.0)
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'fp32_split'],
                     help='operand precision of the MFMA kernels for the headline number')
@@ -392,9 +393,9 @@ def main():
                               'ms_per_step': top['ms_per_step'], 'whole_step': whole}
         traced_ms = sum(r['ms_per_step'] for r in rows)
         result['kernels'] = [{k: r[k] for k in ('kernel', 'bound', 'achieved', 'unit', 'frac', 'ms_per_step',
-                                                'launches_per_step', 'avg_launch_us')} for r in rows[:16]]
+                                                'launches_per_step', 'avg_launch_us')} for r in rows[:args.kernel_rows]]
         result['kernels_note'] = (f'{len(rows)} kernel symbols of this library, {round(traced_ms, 3)} ms per eager step '
-                                  f'in all; the first {min(16, len(rows))} listed')
+                                  f'in all; the first {min(args.kernel_rows, len(rows))} listed')
     elif whole is not None:
         result['roofline'] = {'whole_step': whole}
     if args.mode == 'train' and not args.no_extras and world == 1:

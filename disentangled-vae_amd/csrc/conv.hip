@@ -103,7 +103,6 @@ struct ConvArgs {
   const float* in_b;
   float* dx_out;
   int mt0;          // tiled kernels: first M tile of this launch (a layer may be split over two launches)
-  int round_bf16;   // row-ring kernels in bf16 mode: operands rounded to bf16 on their way into registers / LDS
 };
 
 // A operand of the forward implicit GEMMs.  MODE 0: conv (16 taps, input pixel 2*o-1+k);
@@ -525,6 +524,44 @@ __global__ void __launch_bounds__(256) conv_c1_kernel(ConvArgs g) {
   }
 }
 
+// Element type and multiply step of the row-ring kernels.  A lane's MFMA operand piece is four consecutive
+// channels (or pixels) of one row: with f32 operands those are the operands of four v_mfma_f32_16x16x4_f32
+// (k = kq of each), with bf16 operands they are ONE 8-byte operand of v_mfma_f32_16x16x16_bf16 (k = 4kq..4kq+3),
+// so the bf16 variants keep their rings and their register-resident filters as bf16 (rounded to nearest even
+// once, on the way in) and issue a quarter of the MFMAs at twice the rate each.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <bool BF>
+struct RowOps;
+template <>
+struct RowOps<false> {
+  typedef float elem;
+  typedef f32x4 frag;
+  static constexpr int PAD = 4;       // elements: 16 bytes
+  static __device__ __forceinline__ frag make(const f32x4& v) { return v; }
+};
+template <>
+struct RowOps<true> {
+  typedef unsigned short elem;
+  typedef s16x4 frag;
+  static constexpr int PAD = 8;       // elements: 16 bytes
+  static __device__ __forceinline__ frag make(const f32x4& v) {
+    uint2 w;
+    w.x = pack_bf16(v[0], v[1]);
+    w.y = pack_bf16(v[2], v[3]);
+    return __builtin_bit_cast(s16x4, w);
+  }
+  static __device__ __forceinline__ f32x4 mma(const frag& a, const frag& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+  }
+};
+// the weight-gradient kernels' K is pixels: a lane's four pixels 4kq..4kq+3 of one channel, read one by one
+__device__ __forceinline__ s16x4 bf_quad(float k0, float k1, float k2, float k3) {
+  uint2 w;
+  w.x = pack_bf16(k0, k1);
+  w.y = pack_bf16(k2, k3);
+  return __builtin_bit_cast(s16x4, w);
+}
+
 // Transposed convolution with few channels (Cin*Cout <= 2048) on frames at least sixteen pixels wide:
 // too little work per pixel for a tiled GEMM whose K loop is four taps deep.  A workgroup is four waves
 // = the four sub-pixel phases; each wave keeps its phase's whole filter [Cout][4 taps][Cin] in
@@ -542,28 +579,27 @@ __global__ void __launch_bounds__(256) conv_c1_kernel(ConvArgs g) {
 // BNIN: the input is a gradient that still has to go through its own layer's BatchNorm backward
 // (x = du, in_y = that layer's raw output, dx = scale*dz + A*y + B formed on the way into LDS and
 // written to dx_out for the rows the workgroup owns), as in conv_rows_kernel.
-template <int CIN, int COUT, int WAVES_PER_EU, bool XF, bool BNS, bool BNIN>
+template <int CIN, int COUT, int WAVES_PER_EU, bool XF, bool BNS, bool BNIN, bool BF>
 __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs g) {
+  typedef RowOps<BF> R;
+  typedef typename R::frag frag_t;
   constexpr int NU = CIN / 16, NCB = COUT / 16;
-  constexpr int PS = CIN + 4;                       // pixel stride in LDS: 16-byte reads without bank conflicts
-  constexpr int C4 = CIN / 4;                       // 16-byte pieces per pixel
+  constexpr int PS = CIN + R::PAD;                  // pixel stride in LDS: a lane's reads without bank conflicts
+  constexpr int C4 = CIN / 4;                       // four-channel pieces per pixel
   constexpr int NLD = (ROWS_WMAX * C4 + 255) / 256; // 16-byte pieces of a row per thread, at most
-  __shared__ __attribute__((aligned(16))) float ring[4][(ROWS_WMAX + 2) * PS];
+  __shared__ __attribute__((aligned(16))) typename R::elem ring[4][(ROWS_WMAX + 2) * PS];
   const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6, ph = phase >> 1, pw = phase & 1;
   const int i16 = lane & 15, kq = lane >> 4;
   const int W = g.W, H = g.H;
   // component m of wa[cb][t][u] multiplies channel 16u + 4kq + m of tap t into output channel 16cb + i16
-  f32x4 wa[NCB][4][NU];
+  frag_t wa[NCB][4][NU];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int u = 0; u < NU; ++u)
-      {
-        const f32x4 w = ldg4(g.wp + (((int64_t)phase * COUT + 16 * cb + i16) * 4 + t) * CIN + 16 * u + 4 * kq);
-        wa[cb][t][u] = g.round_bf16 ? round_bf16(w) : w;
-      }
+        wa[cb][t][u] = R::make(ldg4(g.wp + (((int64_t)phase * COUT + 16 * cb + i16) * 4 + t) * CIN + 16 * u + 4 * kq));
   // loader role: this thread's pieces of a row are pieces threadIdx.x + 256 j; their channel offset is
   // the same for every j (C4 divides 256)
   const int lc4 = threadIdx.x % C4;
@@ -596,7 +632,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
   // zero pixels left and right of every row slot
   for (int i = threadIdx.x; i < 4 * 2 * PS; i += 256) {
     const int slot = i / (2 * PS), r = i % (2 * PS);
-    ring[slot][(r < PS ? 0 : (W + 1) * PS) + r % PS] = 0.f;
+    ring[slot][(r < PS ? 0 : (W + 1) * PS) + r % PS] = 0;
   }
 
   // Rows are numbered over the whole batch (row = image * H + a): consecutive rows are consecutive in
@@ -620,7 +656,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
     }
   };
   auto deposit = [&](int64_t row) {          // transform and write the fetched row into its slot
-    float* dst = ring[row & 3];
+    typename R::elem* dst = ring[row & 3];
     const bool owned = BNIN && row >= r0 && row < r1;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
@@ -642,8 +678,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(z[e], zs[e]);
         }
-        if (g.round_bf16) v = round_bf16(v);
-        *reinterpret_cast<f32x4*>(dst + (1 + f / C4) * PS + 4 * lc4) = v;
+        *reinterpret_cast<frag_t*>(dst + (1 + f / C4) * PS + 4 * lc4) = R::make(v);
       }
     }
   };
@@ -673,23 +708,30 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
       for (int th = 0; th < 2; ++th) {
         const int arow = a + ph - th;
         if (arow < 0 || arow >= H) continue;          // the tap row is above or below the frame
-        const float* rowp = ring[(r + ph - th) & 3];
-        f32x4 xv[2][NU];
+        const typename R::elem* rowp = ring[(r + ph - th) & 3];
+        frag_t xv[2][NU];
 #pragma unroll
         for (int tw = 0; tw < 2; ++tw)
 #pragma unroll
           for (int u = 0; u < NU; ++u)
-            xv[tw][u] = *reinterpret_cast<const f32x4*>(rowp + (1 + 16 * j + i16 + pw - tw) * PS + 16 * u + 4 * kq);
+            xv[tw][u] = *reinterpret_cast<const frag_t*>(rowp + (1 + 16 * j + i16 + pw - tw) * PS + 16 * u + 4 * kq);
 #pragma unroll
         for (int tw = 0; tw < 2; ++tw)
 #pragma unroll
-          for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
+          for (int u = 0; u < NU; ++u) {
+            if constexpr (BF) {
 #pragma unroll
               for (int cb = 0; cb < NCB; ++cb)
-                acc[cb][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][2 * th + tw][u][e], xv[tw][u][e],
-                                                                      acc[cb][e & 1], 0, 0, 0);
+                acc[cb][u & 1] = R::mma(wa[cb][2 * th + tw][u], xv[tw][u], acc[cb][u & 1]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+                  acc[cb][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cb][2 * th + tw][u][e], xv[tw][u][e],
+                                                                        acc[cb][e & 1], 0, 0, 0);
+            }
+          }
       }
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
@@ -740,13 +782,15 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
 // output channels each ([16][4 taps][Cin] = 128 registers per lane at Cin = 128).  A group of sixteen
 // pixels is two rows of eight, so the row a lane reads depends on the lane: rows outside the frame are
 // redirected to a ninth, all-zero slot instead of being skipped.
-template <int CIN, int WAVES_PER_EU, bool XF, bool BNS>
+template <int CIN, int WAVES_PER_EU, bool XF, bool BNS, bool BF>
 __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows8_kernel(ConvArgs g) {
+  typedef RowOps<BF> R;
+  typedef typename R::frag frag_t;
   constexpr int COUT = 64, W = 8, NU = CIN / 16;
-  constexpr int PS = CIN + 4, C4 = CIN / 4;
+  constexpr int PS = CIN + R::PAD, C4 = CIN / 4;
   constexpr int SLOT = (W + 2) * PS;
   constexpr int NLD = (W * C4 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float ring[9 * SLOT];
+  __shared__ __attribute__((aligned(16))) typename R::elem ring[9 * SLOT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // The four phases of a row run read the same input rows.  Workgroups go to the eight XCDs in turn
   // (id mod 8), so with a multiple of eight runs the four are numbered eight apart: same XCD, same L2.
@@ -761,14 +805,12 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows8_kernel(ConvArg
   const int i16 = lane & 15, kq = lane >> 4;
   const int H = g.H;
   // component m of wa[t][u] multiplies channel 16u + 4kq + m of tap t into output channel 16 wave + i16
-  f32x4 wa[4][NU];
+  frag_t wa[4][NU];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const f32x4 w = ldg4(g.wp + (((int64_t)phase * COUT + 16 * wave + i16) * 4 + t) * CIN + 16 * u + 4 * kq);
-      wa[t][u] = g.round_bf16 ? round_bf16(w) : w;
-    }
+    for (int u = 0; u < NU; ++u)
+      wa[t][u] = R::make(ldg4(g.wp + (((int64_t)phase * COUT + 16 * wave + i16) * 4 + t) * CIN + 16 * u + 4 * kq));
   const int lc4 = threadIdx.x % C4;
   f32x4 sc = (f32x4){1.f, 1.f, 1.f, 1.f}, sh = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float slope = g.in_act == DVAE_ACT_LRELU ? LRELU_SLOPE : 1.f;
@@ -788,9 +830,9 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows8_kernel(ConvArg
   // zero pixels left and right of the eight row slots, and the whole ninth slot
   for (int i = threadIdx.x; i < 8 * 2 * PS; i += 256) {
     const int slot = i / (2 * PS), r = i % (2 * PS);
-    ring[slot * SLOT + (r < PS ? 0 : (W + 1) * PS) + r % PS] = 0.f;
+    ring[slot * SLOT + (r < PS ? 0 : (W + 1) * PS) + r % PS] = 0;
   }
-  for (int i = threadIdx.x; i < SLOT; i += 256) ring[8 * SLOT + i] = 0.f;
+  for (int i = threadIdx.x; i < SLOT; i += 256) ring[8 * SLOT + i] = 0;
 
   // Input rows are numbered over the whole batch; a step takes the row pair (2p, 2p+1), which never
   // straddles two frames (H is even), and reads rows 2p-1 .. 2p+2.  gx workgroups per phase, one per
@@ -811,7 +853,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows8_kernel(ConvArg
     }
   };
   auto deposit = [&](int64_t row, const f32x4 (&raw)[NLD]) {
-    float* dst = ring + (row & 7) * SLOT;
+    typename R::elem* dst = ring + (row & 7) * SLOT;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int f = threadIdx.x + 256 * j;
@@ -823,8 +865,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows8_kernel(ConvArg
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(z[e], zs[e]);
         }
-        if (g.round_bf16) v = round_bf16(v);
-        *reinterpret_cast<f32x4*>(dst + (1 + f / C4) * PS + 4 * lc4) = v;
+        *reinterpret_cast<frag_t*>(dst + (1 + f / C4) * PS + 4 * lc4) = R::make(v);
       }
     }
   };
@@ -854,20 +895,25 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows8_kernel(ConvArg
     for (int th = 0; th < 2; ++th) {
       const int ia = a + ph - th;
       const bool inside = ia >= 0 && ia < H;
-      const float* rowp = ring + (inside ? (int)((arow + ph - th) & 7) : 8) * SLOT;
-      f32x4 xv[2][NU];
+      const typename R::elem* rowp = ring + (inside ? (int)((arow + ph - th) & 7) : 8) * SLOT;
+      frag_t xv[2][NU];
 #pragma unroll
       for (int tw = 0; tw < 2; ++tw)
 #pragma unroll
         for (int u = 0; u < NU; ++u)
-          xv[tw][u] = *reinterpret_cast<const f32x4*>(rowp + (1 + b + pw - tw) * PS + 16 * u + 4 * kq);
+          xv[tw][u] = *reinterpret_cast<const frag_t*>(rowp + (1 + b + pw - tw) * PS + 16 * u + 4 * kq);
 #pragma unroll
       for (int tw = 0; tw < 2; ++tw)
 #pragma unroll
-        for (int u = 0; u < NU; ++u)
+        for (int u = 0; u < NU; ++u) {
+          if constexpr (BF) {
+            acc[u & 1] = R::mma(wa[2 * th + tw][u], xv[tw][u], acc[u & 1]);
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            acc[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[2 * th + tw][u][e], xv[tw][u][e], acc[e & 1], 0, 0, 0);
+            for (int e = 0; e < 4; ++e)
+              acc[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[2 * th + tw][u][e], xv[tw][u][e], acc[e & 1], 0, 0, 0);
+          }
+        }
     }
     // D: row = output channel 16 wave + 4kq + e, column = pixel i16
     const f32x4 v = acc[0] + acc[1];
@@ -920,26 +966,29 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows8_kernel(ConvArg
 // dvae_bn_bwd_coeffs_f32) on its way into LDS -- the elementwise BatchNorm-backward pass over the
 // tensor disappears.  The rows a workgroup owns (not its halo rows) are also written to dx_out for
 // the weight-gradient kernel.
-template <int CIN, int COUT, int WAVES_PER_EU, bool XF, bool BNS, bool BNIN>
+template <int CIN, int COUT, int WAVES_PER_EU, bool XF, bool BNS, bool BNIN, bool BF>
 __global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvArgs g) {
+  typedef RowOps<BF> R;
+  typedef typename R::frag frag_t;
   constexpr int NU = CIN / 16, NT = COUT * 4;
-  constexpr int PS = CIN + 4;                       // pixel stride in LDS: 16-byte reads without bank conflicts
-  constexpr int C4 = CIN / 4;                       // 16-byte pieces per pixel
+  constexpr int PS = CIN + R::PAD;                  // pixel stride in LDS: a lane's reads without bank conflicts
+  constexpr int C4 = CIN / 4;                       // four-channel pieces per pixel
   constexpr int WMAX = BNIN ? 32 : 64;              // widest frame (the BNIN variant holds two tensors' rows)
   constexpr int NLD = (WMAX * C4 + NT - 1) / NT;    // 16-byte pieces of a row per thread, at most
-  extern __shared__ __attribute__((aligned(16))) float ring[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring_bytes[];
+  typename R::elem* const ring = reinterpret_cast<typename R::elem*>(ring_bytes);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, kq = lane >> 4;
   const int W = g.W, H = g.H, Wo = W >> 1, Ho = H >> 1;
   const int half = Wo + 1;                          // pixels of one parity, with its zero pixel
   const int slot_floats = 2 * half * PS;
   // component m of wa[t][u] multiplies channel 16u + 4kq + m of tap t into output channel 16 wave + i16
-  f32x4 wa[16][NU];
+  frag_t wa[16][NU];
 #pragma unroll
   for (int t = 0; t < 16; ++t)
 #pragma unroll
     for (int u = 0; u < NU; ++u)
-      wa[t][u] = ldg4(g.wp + ((int64_t)(16 * wave + i16) * 16 + t) * CIN + 16 * u + 4 * kq);
+      wa[t][u] = R::make(ldg4(g.wp + ((int64_t)(16 * wave + i16) * 16 + t) * CIN + 16 * u + 4 * kq));
   const int lc4 = threadIdx.x % C4;
   f32x4 sc = (f32x4){1.f, 1.f, 1.f, 1.f}, sh = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float slope = g.in_act == DVAE_ACT_LRELU ? LRELU_SLOPE : 1.f;
@@ -965,7 +1014,7 @@ __global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvA
   // the zero pixels of every slot: even columns' at index Wo, odd columns' at index 0 of their half
   for (int i = threadIdx.x; i < 8 * 2 * PS; i += NT) {
     const int slot = i / (2 * PS), r = i % (2 * PS);
-    ring[slot * slot_floats + (r < PS ? Wo * PS : half * PS) + r % PS] = 0.f;
+    ring[slot * slot_floats + (r < PS ? Wo * PS : half * PS) + r % PS] = 0;
   }
 
   // Output rows are numbered over the whole batch (row = image * Ho + oa); output row r reads input
@@ -991,7 +1040,7 @@ __global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvA
     }
   };
   auto deposit = [&](int64_t row, const Raw& raw) {   // transform, split by column parity, store
-    float* dst = ring + (row & 7) * slot_floats;
+    typename R::elem* dst = ring + (row & 7) * slot_floats;
     const bool owned = BNIN && row >= 2 * r0 && row < 2 * r1;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
@@ -1015,7 +1064,7 @@ __global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvA
         }
         const int px = f / C4;
         const int at = (px & 1) ? half + 1 + (px >> 1) : (px >> 1);
-        *reinterpret_cast<f32x4*>(dst + at * PS + 4 * lc4) = v;
+        *reinterpret_cast<frag_t*>(dst + at * PS + 4 * lc4) = R::make(v);
       }
     }
   };
@@ -1045,22 +1094,27 @@ __global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvA
       for (int kh = 0; kh < 4; ++kh) {
         const int hin = 2 * oa - 1 + kh;
         if (hin < 0 || hin >= H) continue;          // the tap row is above or below the frame
-        const float* rowp = ring + ((2 * r - 1 + kh) & 7) * slot_floats;
+        const typename R::elem* rowp = ring + ((2 * r - 1 + kh) & 7) * slot_floats;
         // input column 2ob-1+kw: kw 0 -> odd[ob-1], 1 -> even[ob], 2 -> odd[ob], 3 -> even[ob+1]
         const int at[4] = {half + ob, ob, half + ob + 1, ob + 1};
-        f32x4 xv[4][NU];
+        frag_t xv[4][NU];
 #pragma unroll
         for (int kw = 0; kw < 4; ++kw)
 #pragma unroll
           for (int u = 0; u < NU; ++u)
-            xv[kw][u] = *reinterpret_cast<const f32x4*>(rowp + at[kw] * PS + 16 * u + 4 * kq);
+            xv[kw][u] = *reinterpret_cast<const frag_t*>(rowp + at[kw] * PS + 16 * u + 4 * kq);
 #pragma unroll
         for (int kw = 0; kw < 4; ++kw)
 #pragma unroll
-          for (int u = 0; u < NU; ++u)
+          for (int u = 0; u < NU; ++u) {
+            if constexpr (BF) {
+              acc[(kw * NU + u) & 1] = R::mma(wa[4 * kh + kw][u], xv[kw][u], acc[(kw * NU + u) & 1]);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              acc[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[4 * kh + kw][u][e], xv[kw][u][e], acc[e & 1], 0, 0, 0);
+              for (int e = 0; e < 4; ++e)
+                acc[e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[4 * kh + kw][u][e], xv[kw][u][e], acc[e & 1], 0, 0, 0);
+            }
+          }
       }
       // D: row = output channel 16 wave + 4kq + e, column = output pixel ob
       const f32x4 v = acc[0] + acc[1];
@@ -1149,6 +1203,11 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   typedef Tile<128, 128, 2, 2, true, true> T128;
   typedef Tile<128, 64, 4, 1, true, true> T64;
   typedef Tile<128, 32, 4, 1, true, true> T32;
+#define ROWS_K(CI, CO, WPE, XF_, BNS_, BNIN_)                                                            \
+  {                                                                                                      \
+    if (bf) DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, XF_, BNS_, BNIN_, true>), grid, dim3(256), 0, stream, g); \
+    else DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, XF_, BNS_, BNIN_, false>), grid, dim3(256), 0, stream, g);   \
+  }
 #define ROWS_LAUNCH(CI, CO, WPE, RESIDENT)                                                               \
   if (MODE == 1 && g.Cin == CI && g.Cout == CO && g.W >= 16 && g.W <= ROWS_WMAX &&                 \
       aligned16(g.y) && (!bns || aligned16(g.bn_y)) &&                                                    \
@@ -1158,26 +1217,25 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     const bool xf = g.in_scale != nullptr || g.in_act != DVAE_ACT_NONE;                                   \
     DVAE_WORK(2.0 * (double)g.M * phases * g.Cout * g.K, DVAE_UNIT_FLOP);                                 \
     if (g.in_y != nullptr && bns)                                                                         \
-      DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, false, true, true>), grid, dim3(256), 0, stream, g); \
+      ROWS_K(CI, CO, WPE, false, true, true)                                                              \
     else if (g.in_y != nullptr) {                                                                         \
       dvae_set_error("%s: a BatchNorm-backward input needs the fused statistics of the layer below", name); \
       return -EINVAL;                                                                                     \
     } else if (bns && xf)                                                                                 \
-      DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, true, true, false>), grid, dim3(256), 0, stream, g); \
+      ROWS_K(CI, CO, WPE, true, true, false)                                                              \
     else if (bns)                                                                                         \
-      DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, false, true, false>), grid, dim3(256), 0, stream, g); \
+      ROWS_K(CI, CO, WPE, false, true, false)                                                             \
     else if (xf)                                                                                          \
-      DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, true, false, false>), grid, dim3(256), 0, stream, g); \
+      ROWS_K(CI, CO, WPE, true, false, false)                                                             \
     else                                                                                                  \
-      DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, false, false, false>), grid, dim3(256), 0, stream, g); \
+      ROWS_K(CI, CO, WPE, false, false, false)                                                            \
     DVAE_LAUNCH_CHECK(name);                                                                              \
     return 0;                                                                                             \
   }
-  // (in bf16 mode as well, with operands rounded to bf16 on the way in: at these sizes the row ring
-  // with the f32 MFMA beats the tiled bf16 kernel)
   ROWS_LAUNCH(32, 16, 2, 4)
   ROWS_LAUNCH(64, 32, 2, 2)
 #undef ROWS_LAUNCH
+#undef ROWS_K
   if (MODE == 1 && g.in_y != nullptr) {
     dvae_set_error("%s: no kernel takes a BatchNorm-backward input at this shape (see dvae_deconv4s2_bnin_supported)", name);
     return -EINVAL;
@@ -1189,41 +1247,53 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     const bool xf = g.in_scale != nullptr || g.in_act != DVAE_ACT_NONE;
     const dim3 grid(gx * 4);
     DVAE_WORK(2.0 * (double)g.M * phases * g.Cout * g.K, DVAE_UNIT_FLOP);
-    if (bns && xf) DVAE_LAUNCH((deconv_rows8_kernel<128, 2, true, true>), grid, dim3(256), 0, stream, g);
-    else if (bns) DVAE_LAUNCH((deconv_rows8_kernel<128, 2, false, true>), grid, dim3(256), 0, stream, g);
-    else if (xf) DVAE_LAUNCH((deconv_rows8_kernel<128, 2, true, false>), grid, dim3(256), 0, stream, g);
-    else DVAE_LAUNCH((deconv_rows8_kernel<128, 2, false, false>), grid, dim3(256), 0, stream, g);
+#define ROWS8_K(XF_, BNS_)                                                                              \
+  {                                                                                                     \
+    if (bf) DVAE_LAUNCH((deconv_rows8_kernel<128, 2, XF_, BNS_, true>), grid, dim3(256), 0, stream, g); \
+    else DVAE_LAUNCH((deconv_rows8_kernel<128, 2, XF_, BNS_, false>), grid, dim3(256), 0, stream, g);   \
+  }
+    if (bns && xf) ROWS8_K(true, true)
+    else if (bns) ROWS8_K(false, true)
+    else if (xf) ROWS8_K(true, false)
+    else ROWS8_K(false, false)
+#undef ROWS8_K
     DVAE_LAUNCH_CHECK(name);
     return 0;
   }
+#define CROWS_K(CI, CO, WPE, XF_, BNS_, BNIN_)                                                           \
+  {                                                                                                      \
+    if (bf) DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, XF_, BNS_, BNIN_, true>), grid, dim3(CO * 4), lds, stream, g); \
+    else DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, XF_, BNS_, BNIN_, false>), grid, dim3(CO * 4), lds, stream, g);   \
+  }
 #define CONV_ROWS_LAUNCH(CI, CO, WPE, RESIDENT)                                                           \
-  if (MODE == 0 && !bf && g.Cin == CI && g.Cout == CO && g.W >= 32 && g.W <= 64 && g.H >= 2 &&            \
+  if (MODE == 0 && g.Cin == CI && g.Cout == CO && g.W >= 32 && g.W <= 64 && g.H >= 2 &&            \
       aligned16(g.y) && (!bns || aligned16(g.bn_y)) &&                                                    \
       (!g.in_scale || (aligned16(g.in_scale) && aligned16(g.in_shift)))) {                                \
     const dim3 grid((unsigned)conv_parts_written(g.M, 1));                                                \
     g.mtiles = (int)grid.x < 256 * RESIDENT ? (int)grid.x : 256 * RESIDENT;                               \
-    const size_t lds = (size_t)8 * 2 * (g.W / 2 + 1) * (CI + 4) * sizeof(float);                          \
+    const size_t lds = (size_t)8 * 2 * (g.W / 2 + 1) * (bf ? (CI + 8) * 2 : (CI + 4) * 4);                \
     const bool xf = g.in_scale != nullptr || g.in_act != DVAE_ACT_NONE;                                   \
     DVAE_WORK(2.0 * (double)g.M * g.Cout * g.K, DVAE_UNIT_FLOP);                                          \
     if (g.in_y != nullptr && bns)                                                                         \
-      DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, false, true, true>), grid, dim3(CO * 4), lds, stream, g); \
+      CROWS_K(CI, CO, WPE, false, true, true) \
     else if (g.in_y != nullptr) {                                                                         \
       dvae_set_error("%s: a BatchNorm-backward input needs the fused statistics of the layer below", name); \
       return -EINVAL;                                                                                     \
     } else if (bns && xf)                                                                                 \
-      DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, true, true, false>), grid, dim3(CO * 4), lds, stream, g); \
+      CROWS_K(CI, CO, WPE, true, true, false) \
     else if (bns)                                                                                         \
-      DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, false, true, false>), grid, dim3(CO * 4), lds, stream, g); \
+      CROWS_K(CI, CO, WPE, false, true, false) \
     else if (xf)                                                                                          \
-      DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, true, false, false>), grid, dim3(CO * 4), lds, stream, g); \
+      CROWS_K(CI, CO, WPE, true, false, false) \
     else                                                                                                  \
-      DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, false, false, false>), grid, dim3(CO * 4), lds, stream, g); \
+      CROWS_K(CI, CO, WPE, false, false, false) \
     DVAE_LAUNCH_CHECK(name);                                                                              \
     return 0;                                                                                             \
   }
   CONV_ROWS_LAUNCH(32, 64, 2, 2)
   CONV_ROWS_LAUNCH(16, 32, 2, 4)
 #undef CONV_ROWS_LAUNCH
+#undef CROWS_K
   if (g.in_y != nullptr) {
     dvae_set_error("%s: no kernel takes a BatchNorm-backward input at this shape (see dvae_conv4s2_bnin_supported)", name);
     return -EINVAL;
@@ -1319,7 +1389,6 @@ static int conv4s2_fwd_impl(const char* name, const float* x, const float* in_sc
   g.lc = is_pow2(Cin) ? ilog2(Cin) : -1;
   g.cin32 = Cin % 32 == 0;
   g.bn_y = bn.y; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_invstd = bn.invstd;
-  g.round_bf16 = 0;
   g.in_y = bi.y; g.in_a = bi.a; g.in_b = bi.b; g.dx_out = bi.dx_out;
   DVAE_REQUIRE(bi.y == nullptr || (in_scale && in_shift && bi.a && bi.b && bi.dx_out && aligned16(bi.y) &&
                                    aligned16(bi.a) && aligned16(bi.b) && aligned16(bi.dx_out)),
@@ -1345,7 +1414,6 @@ static int deconv4s2_fwd_impl(const char* name, const float* x, const float* in_
   g.lc = is_pow2(Cin) ? ilog2(Cin) : -1;
   g.cin32 = Cin % 32 == 0;
   g.bn_y = bn.y; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_invstd = bn.invstd;
-  g.round_bf16 = dvae_mfma_precision() == DVAE_PRECISION_BF16;
   g.in_y = bi.y; g.in_a = bi.a; g.in_b = bi.b; g.dx_out = bi.dx_out;
   DVAE_REQUIRE(bi.y == nullptr || (in_scale && in_shift && bi.a && bi.b && bi.dx_out && aligned16(bi.y) &&
                                    aligned16(bi.a) && aligned16(bi.b) && aligned16(bi.dx_out)),
@@ -1378,7 +1446,7 @@ extern "C" int dvae_conv4s2_dgrad_bnstat_f32(const float* x, const float* wp, fl
 
 extern "C" int dvae_conv4s2_bnin_supported(int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
   (void)H;
-  return dvae_mfma_precision() != DVAE_PRECISION_BF16 && Cin == 32 && Cout == 64 && W == 32;
+  return Cin == 32 && Cout == 64 && W == 32;
 }
 
 extern "C" int dvae_conv4s2_dgrad_bnstat_bnin_f32(const float* du_in, const float* in_y, const float* in_scale,
@@ -1405,7 +1473,7 @@ extern "C" int dvae_deconv4s2_dgrad_bnstat_f32(const float* x, const float* wp, 
 
 extern "C" int dvae_deconv4s2_bnin_supported(int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
   (void)H;
-  return dvae_mfma_precision() != DVAE_PRECISION_BF16 && Cin == 32 && Cout == 16 && (W == 16 || W == 32);
+  return Cin == 32 && Cout == 16 && (W == 16 || W == 32);
 }
 
 extern "C" int dvae_deconv4s2_dgrad_bnstat_bnin_f32(const float* du_in, const float* in_y, const float* in_scale,
@@ -1744,7 +1812,7 @@ static int wgrad_reduce_runs(int split, int64_t total) {
 // right of every Q row stand for the frame's edges, and taps above/below the frame are skipped.  Wave
 // w owns the sixteen rows 16 (w % NRB) of the gradient and an equal share of the taps.  Each workgroup
 // writes its partial gradient as one slab for wgrad_reduce_kernel.
-template <int C1, int C2, int WAVES_PER_EU, bool XP, bool XQ>
+template <int C1, int C2, int WAVES_PER_EU, bool XP, bool XQ, bool BF>
 __global__ void __launch_bounds__(256, WAVES_PER_EU) wgrad_rows_kernel(WgradArgs g) {
   constexpr int NRB = C1 / 16;            // row blocks of the gradient
   constexpr int CPARTS = 4 / NRB;         // the taps are shared between this many waves per row block
@@ -1875,6 +1943,22 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) wgrad_rows_kernel(WgradArgs
         if (hin < 0 || hin >= 2 * Hs) continue;    // the tap row is above or below the frame
         const float* qrow = qring + ((2 * r - 1 + dh) & 7) * qslot;
         // Q pixel of (b, dw) is column 2b-1+dw, stored at index 2b+dw
+        if constexpr (BF) {
+          // the lane's four pixels are the four k of one bf16 MFMA operand
+          const s16x4 af = bf_quad(av[0], av[1], av[2], av[3]);
+#pragma unroll
+          for (int dw = 0; dw < 4; ++dw) {
+            float bq[4][NCB];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int cb = 0; cb < NCB; ++cb) bq[e][cb] = qrow[(2 * (b0 + e) + dw) * PSQ + 16 * cb + i16];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+              acc[dl][dw][cb] = RowOps<true>::mma(af, bf_quad(bq[0][cb], bq[1][cb], bq[2][cb], bq[3][cb]), acc[dl][dw][cb]);
+          }
+          continue;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float bv[4][NCB];
@@ -1918,7 +2002,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) wgrad_rows_kernel(WgradArgs
 // layer's raw output; a row becomes scale*dz + A*y + B on its way into LDS).  Every Q row is met by
 // exactly two filter rows; the workgroups of filter rows 1 and 2 between them meet each row once and
 // write the finished rows to dx_out for the data-gradient kernel.
-template <bool XP, bool XQ, bool BNQ>
+template <bool XP, bool XQ, bool BNQ, bool BF>
 __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
   constexpr int C1 = 128, C2 = 64, Ws = 8, WQ = 16, NCB = C2 / 16;
   constexpr int PSP = C1 + 4, PSQ = C2 + 2, P4 = C1 / 4, Q4 = C2 / 4;
@@ -2033,8 +2117,30 @@ __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
   __syncthreads();
   for (int64_t p = p0; p < p1; ++p) {
     fetch(p + 1, raw);
+    if constexpr (BF) {
+      // the lane's four pixels 4kq..4kq+3 (one row of the pair: 4kq+3 < 8 or 4kq >= 8) are the four k of one
+      // bf16 MFMA operand
+      const int h = kq >> 1, b0 = (4 * kq) & 7;
+      const float* prow = pbuf[p & 1][h];
+      const float* qrow = qbuf[p & 1][h];
+      s16x4 af[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+      for (int r = 0; r < 2; ++r) {
+        const float* pa = prow + b0 * PSP + 16 * (2 * wave + r) + i16;
+        af[r] = bf_quad(pa[0], pa[PSP], pa[2 * PSP], pa[3 * PSP]);
+      }
+#pragma unroll
+      for (int dw = 0; dw < 4; ++dw)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const float* qa = qrow + (2 * b0 + dw) * PSQ + 16 * cb + i16;
+          const s16x4 bfq = bf_quad(qa[0], qa[2 * PSQ], qa[4 * PSQ], qa[6 * PSQ]);
+#pragma unroll
+          for (int r = 0; r < 2; ++r) acc[r][dw][cb] = RowOps<true>::mma(af[r], bfq, acc[r][dw][cb]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < (BF ? 0 : 4); ++e) {
       const int pos = 4 * kq + e, h = pos >> 3, b = pos & 7;     // this lane's pixel of the K group
       const float* prow = pbuf[p & 1][h];
       const float* qrow = qbuf[p & 1][h];
@@ -2076,7 +2182,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
 // into LDS pixel by pixel (zeros where the tap leaves the frame).  Wave w owns gradient rows
 // 64w .. 64w+63.  The sixteen workgroups of a split are numbered so that they land on one XCD close
 // together in time and share the frame through that XCD's L2.
-template <bool XP, bool XQ>
+template <bool XP, bool XQ, bool BF>
 __global__ void __launch_bounds__(256, 2) wgrad_img4_kernel(WgradArgs g) {
   constexpr int C1 = 256, C2 = 128, NCB = C2 / 16;
   constexpr int PSP = C1 + 4, PSQ = C2 + 4, P4 = C1 / 4, Q4 = C2 / 4;
@@ -2163,8 +2269,24 @@ __global__ void __launch_bounds__(256, 2) wgrad_img4_kernel(WgradArgs g) {
     fetch(n + 1, raw);
     const float* pp = pbuf[n & 1];
     const float* qq = qbuf[n & 1];
+    if constexpr (BF) {
+      // the lane's four pixels 4kq..4kq+3 are the four k of one bf16 MFMA operand
+      s16x4 af[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+      for (int r = 0; r < 4; ++r) {
+        const float* pa = pp + 4 * kq * PSP + 16 * (4 * wave + r) + i16;
+        af[r] = bf_quad(pa[0], pa[PSP], pa[2 * PSP], pa[3 * PSP]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const float* qa = qq + 4 * kq * PSQ + 16 * cb + i16;
+        const s16x4 bfq = bf_quad(qa[0], qa[PSQ], qa[2 * PSQ], qa[3 * PSQ]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r][cb] = RowOps<true>::mma(af[r], bfq, acc[r][cb]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < (BF ? 0 : 4); ++e) {
       const int pos = 4 * kq + e;                 // this lane's pixel of the K group
       float av[4], bv[NCB];
 #pragma unroll
@@ -2203,7 +2325,7 @@ static bool wgrad_rows_shape(int64_t C1, int64_t C2, int64_t Ws) {
 
 static WgradPlan wgrad_plan(int64_t Mtot, int64_t Ws, int64_t C1, int64_t C2, int64_t Hs = 0) {
   WgradPlan p;
-  if (C1 == 256 && C2 == 128 && Ws == 4 && Hs == 4 && Mtot >= 16 * 32 && dvae_mfma_precision() != DVAE_PRECISION_BF16) {
+  if (C1 == 256 && C2 == 128 && Ws == 4 && Hs == 4 && Mtot >= 16 * 32) {
     // sixteen workgroups (filter taps) per slab; 16 x 32 = two workgroups per compute unit
     p.bm = -3;
     p.tm = p.tn = 1;
@@ -2221,7 +2343,7 @@ static WgradPlan wgrad_plan(int64_t Mtot, int64_t Ws, int64_t C1, int64_t C2, in
     p.ktiles_per_split = 0;
     return p;
   }
-  if (C1 == 128 && C2 == 64 && Ws == 8 && Mtot >= 16 && dvae_mfma_precision() != DVAE_PRECISION_BF16) {
+  if (C1 == 128 && C2 == 64 && Ws == 8 && Mtot >= 16) {
     // four workgroups (filter rows) per slab; 4 x 128 = two workgroups per compute unit
     p.bm = -2;
     p.tm = p.tn = 1;
@@ -2230,7 +2352,7 @@ static WgradPlan wgrad_plan(int64_t Mtot, int64_t Ws, int64_t C1, int64_t C2, in
     p.ktiles_per_split = 0;
     return p;
   }
-  if (wgrad_rows_shape(C1, C2, Ws) && dvae_mfma_precision() != DVAE_PRECISION_BF16) {
+  if (wgrad_rows_shape(C1, C2, Ws)) {
     // one slab per workgroup; as many workgroups as are resident at once
     p.bm = -1;
     p.tm = p.tn = 1;
@@ -2287,6 +2409,13 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
   const WgradPlan p = wgrad_plan(g.Mtot, Ws, C1, C2, Hs);
   g.ktiles_per_split = p.ktiles_per_split;
   hipStream_t s = ST(stream);
+  const bool wbf = dvae_mfma_precision() == DVAE_PRECISION_BF16;
+  // a row-ring kernel in the variant of the current MFMA precision
+#define WG_BF(NAME, LDS, ...)                                                                           \
+  {                                                                                                     \
+    if (wbf) DVAE_LAUNCH((NAME<__VA_ARGS__, true>), grid, dim3(256), LDS, s, g);                        \
+    else DVAE_LAUNCH((NAME<__VA_ARGS__, false>), grid, dim3(256), LDS, s, g);                           \
+  }
   DVAE_REQUIRE(q_y == nullptr || (p.bm == -2 && q_scale && q_shift && q_a && q_b && dx_out && aligned16(q_y) &&
                                   aligned16(q_a) && aligned16(q_b) && aligned16(dx_out)),
                "conv4s2_wgrad: a BatchNorm-backward Q is only taken where dvae_conv4s2_wgrad_bnq_supported says so, "
@@ -2298,10 +2427,10 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
                  "conv4s2_wgrad: scale/shift vectors must be 16-byte aligned");
     const dim3 grid((unsigned)p.split * 16);
     const bool xp = p_scale != nullptr || p_act != DVAE_ACT_NONE, xq = q_scale != nullptr || q_act != DVAE_ACT_NONE;
-    if (xp && xq) DVAE_LAUNCH((wgrad_img4_kernel<true, true>), grid, dim3(256), 0, s, g);
-    else if (xp) DVAE_LAUNCH((wgrad_img4_kernel<true, false>), grid, dim3(256), 0, s, g);
-    else if (xq) DVAE_LAUNCH((wgrad_img4_kernel<false, true>), grid, dim3(256), 0, s, g);
-    else DVAE_LAUNCH((wgrad_img4_kernel<false, false>), grid, dim3(256), 0, s, g);
+    if (xp && xq) WG_BF(wgrad_img4_kernel, 0, true, true)
+    else if (xp) WG_BF(wgrad_img4_kernel, 0, true, false)
+    else if (xq) WG_BF(wgrad_img4_kernel, 0, false, true)
+    else WG_BF(wgrad_img4_kernel, 0, false, false)
   } else if (p.bm == -2) {
     DVAE_REQUIRE(Hs >= 2, "conv4s2_wgrad: Hs must be at least 2 at this shape");
     DVAE_REQUIRE((!p_scale || (aligned16(p_scale) && aligned16(p_shift))) && (!q_scale || (aligned16(q_scale) && aligned16(q_shift))),
@@ -2309,12 +2438,12 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
     const dim3 grid((unsigned)p.split * 4);
     const bool xp = p_scale != nullptr || p_act != DVAE_ACT_NONE, xq = q_scale != nullptr || q_act != DVAE_ACT_NONE;
     if (g.q_y != nullptr) {
-      if (xp) DVAE_LAUNCH((wgrad_rows8_kernel<true, false, true>), grid, dim3(256), 0, s, g);
-      else DVAE_LAUNCH((wgrad_rows8_kernel<false, false, true>), grid, dim3(256), 0, s, g);
-    } else if (xp && xq) DVAE_LAUNCH((wgrad_rows8_kernel<true, true, false>), grid, dim3(256), 0, s, g);
-    else if (xp) DVAE_LAUNCH((wgrad_rows8_kernel<true, false, false>), grid, dim3(256), 0, s, g);
-    else if (xq) DVAE_LAUNCH((wgrad_rows8_kernel<false, true, false>), grid, dim3(256), 0, s, g);
-    else DVAE_LAUNCH((wgrad_rows8_kernel<false, false, false>), grid, dim3(256), 0, s, g);
+      if (xp) WG_BF(wgrad_rows8_kernel, 0, true, false, true)
+      else WG_BF(wgrad_rows8_kernel, 0, false, false, true)
+    } else if (xp && xq) WG_BF(wgrad_rows8_kernel, 0, true, true, false)
+    else if (xp) WG_BF(wgrad_rows8_kernel, 0, true, false, false)
+    else if (xq) WG_BF(wgrad_rows8_kernel, 0, false, true, false)
+    else WG_BF(wgrad_rows8_kernel, 0, false, false, false)
   } else if (p.bm == -1) {
     DVAE_REQUIRE((!p_scale || (aligned16(p_scale) && aligned16(p_shift))) && (!q_scale || (aligned16(q_scale) && aligned16(q_shift))),
                  "conv4s2_wgrad: scale/shift vectors must be 16-byte aligned");
@@ -2323,13 +2452,14 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
 #define WGR_LAUNCH(A, B)                                                                                  \
   {                                                                                                       \
     const size_t ldsb = (size_t)(4 * Ws * (A + 4) + 8 * (2 * Ws + 2) * (B + 2)) * sizeof(float);          \
-    if (xp && xq) DVAE_LAUNCH((wgrad_rows_kernel<A, B, 2, true, true>), grid, dim3(256), ldsb, s, g);        \
-    else if (xp) DVAE_LAUNCH((wgrad_rows_kernel<A, B, 2, true, false>), grid, dim3(256), ldsb, s, g);        \
-    else if (xq) DVAE_LAUNCH((wgrad_rows_kernel<A, B, 2, false, true>), grid, dim3(256), ldsb, s, g);        \
-    else DVAE_LAUNCH((wgrad_rows_kernel<A, B, 2, false, false>), grid, dim3(256), ldsb, s, g);               \
+    if (xp && xq) WG_BF(wgrad_rows_kernel, ldsb, A, B, 2, true, true) \
+    else if (xp) WG_BF(wgrad_rows_kernel, ldsb, A, B, 2, true, false) \
+    else if (xq) WG_BF(wgrad_rows_kernel, ldsb, A, B, 2, false, true) \
+    else WG_BF(wgrad_rows_kernel, ldsb, A, B, 2, false, false) \
   }
     if (C1 == 64) WGR_LAUNCH(64, 32) else WGR_LAUNCH(32, 16)
 #undef WGR_LAUNCH
+#undef WG_BF
   } else if (p.bm == 0) {
     const int ncb = (int)((C1 + 15) / 16);
     const dim3 grid((unsigned)p.split);
