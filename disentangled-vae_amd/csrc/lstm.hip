@@ -264,6 +264,9 @@ __global__ void __launch_bounds__(64 * SK_WAVES) skinny_gemm_nt_kernel(SkinnyArg
 // recurrence's critical path is then one kernel per time step instead of two.
 struct LstmBwdStepArgs {
   SkinnyArgs mm;                 // out = dh_{t-1} [B,H], accumulated in place
+  const float* a2; int64_t ld_a2;          // optional second product onto the same output: a2 [B,K2] * wt2 [H,K2]^T
+  const float* wt2; int64_t ld_wt2;
+  int64_t K2;
   const float* gates;            // activated gates of step t-1 [B,4H]
   const float* c_prev; int64_t ld_cprev;   // c_{t-2} (nullptr: zero state)
   const float* c; int64_t ld_c;            // c_{t-1}
@@ -294,16 +297,24 @@ __global__ void __launch_bounds__(64 * SK_WAVES) lstm_bwd_step_kernel(LstmBwdSte
   const float cpv = *(a.c_prev ? a.c_prev + b * a.ld_cprev + j : a.c);
 
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int64_t k0 = (int64_t)wave * 16 * SK_NF; k0 < g.K; k0 += 16 * SK_NF * SK_WAVES) {
-    f32x4 av[SK_NF], bv[SK_NF];
-    frag_load<SK_NF>(ap, rowok, k0 + 4 * q, 16, g.K, av);
-    frag_load<SK_NF>(bp, colok, k0 + 4 * q, 16, g.K, bv);
+#pragma unroll 1
+  for (int seg = 0; seg < 2; ++seg) {
+    // the second product (a stacked decoder: both gradients that reach one hidden state) continues the sums
+    const float* sa = seg == 0 ? ap : (a.a2 ? a.a2 + (rowok ? b0 + i : g.B - 1) * a.ld_a2 : nullptr);
+    const float* sb = seg == 0 ? bp : (a.a2 ? a.wt2 + (colok ? n0 + i : g.N - 1) * a.ld_wt2 : nullptr);
+    const int64_t sK = seg == 0 ? g.K : a.K2;
+    if (sa == nullptr) break;
+    for (int64_t k0 = (int64_t)wave * 16 * SK_NF; k0 < sK; k0 += 16 * SK_NF * SK_WAVES) {
+      f32x4 av[SK_NF], bv[SK_NF];
+      frag_load<SK_NF>(sa, rowok, k0 + 4 * q, 16, sK, av);
+      frag_load<SK_NF>(sb, colok, k0 + 4 * q, 16, sK, bv);
 #pragma unroll
-    for (int f = 0; f < SK_NF; ++f) {
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][0], bv[f][0], acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][1], bv[f][1], acc2, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][2], bv[f][2], acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][3], bv[f][3], acc2, 0, 0, 0);
+      for (int f = 0; f < SK_NF; ++f) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][0], bv[f][0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][1], bv[f][1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][2], bv[f][2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f][3], bv[f][3], acc2, 0, 0, 0);
+      }
     }
   }
   acc += acc2;
@@ -337,12 +348,34 @@ extern "C" int dvae_lstm_bwd_step_f32(const float* dg_t, int64_t ld_dg, const fl
   DVAE_REQUIRE(dg_t && wt && dh_prev && gates && c && dgates && dc_prev, "lstm_bwd_step: null argument");
   DVAE_REQUIRE(K % 4 == 0 && ld_dg % 4 == 0 && ld_wt % 4 == 0, "lstm_bwd_step: K, ld_dg, ld_wt must be multiples of 4");
   DVAE_REQUIRE(aligned16(dg_t) && aligned16(wt), "lstm_bwd_step: 16-byte alignment");
-  LstmBwdStepArgs a{SkinnyArgs{dg_t, ld_dg, wt, ld_wt, dh_prev, ld_dh, B, H, K, 1},
+  LstmBwdStepArgs a{SkinnyArgs{dg_t, ld_dg, wt, ld_wt, dh_prev, ld_dh, B, H, K, 1}, nullptr, 0, nullptr, 0, 0,
                     gates, c_prev, ld_cprev, c, ld_c, dc, ld_dc, dgates, dc_prev, ld_dcprev};
   const dim3 grid((unsigned)ceil_div64(H, 16), (unsigned)ceil_div64(B, 16));
   DVAE_WORK(2.0 * (double)B * H * K, DVAE_UNIT_FLOP);
   DVAE_LAUNCH(lstm_bwd_step_kernel, grid, dim3(64 * SK_WAVES), 0, ST(stream), a);
   DVAE_LAUNCH_CHECK("lstm_bwd_step");
+  return 0;
+}
+
+extern "C" int dvae_lstm_bwd_step2_f32(const float* dg_a, int64_t ld_dga, const float* wt_a, int64_t ld_wta, int64_t Ka,
+                                       const float* dg_b, int64_t ld_dgb, const float* wt_b, int64_t ld_wtb, int64_t Kb,
+                                       float* dh_prev, int64_t ld_dh, const float* dc, int64_t ld_dc,
+                                       const float* gates, const float* c_prev, int64_t ld_cprev, const float* c,
+                                       int64_t ld_c, float* dgates, float* dc_prev, int64_t ld_dcprev, int64_t B,
+                                       int64_t H, dvae_stream_t stream) {
+  DVAE_REQUIRE(B > 0 && H > 0 && Ka > 0, "lstm_bwd_step2: empty");
+  DVAE_REQUIRE(dg_a && wt_a && dh_prev && gates && c && dgates && dc_prev, "lstm_bwd_step2: null argument");
+  DVAE_REQUIRE((dg_b == nullptr) == (wt_b == nullptr) && (dg_b == nullptr || Kb > 0), "lstm_bwd_step2: the second product needs both operands");
+  DVAE_REQUIRE(Ka % 4 == 0 && ld_dga % 4 == 0 && ld_wta % 4 == 0 && aligned16(dg_a) && aligned16(wt_a),
+               "lstm_bwd_step2: K and leading dimensions must be multiples of 4, operands 16-byte aligned");
+  DVAE_REQUIRE(dg_b == nullptr || (Kb % 4 == 0 && ld_dgb % 4 == 0 && ld_wtb % 4 == 0 && aligned16(dg_b) && aligned16(wt_b)),
+               "lstm_bwd_step2: K and leading dimensions must be multiples of 4, operands 16-byte aligned");
+  LstmBwdStepArgs a{SkinnyArgs{dg_a, ld_dga, wt_a, ld_wta, dh_prev, ld_dh, B, H, Ka, 1}, dg_b, ld_dgb, wt_b, ld_wtb,
+                    dg_b ? Kb : 0, gates, c_prev, ld_cprev, c, ld_c, dc, ld_dc, dgates, dc_prev, ld_dcprev};
+  const dim3 grid((unsigned)ceil_div64(H, 16), (unsigned)ceil_div64(B, 16));
+  DVAE_WORK(2.0 * (double)B * H * (Ka + (dg_b ? Kb : 0)), DVAE_UNIT_FLOP);
+  DVAE_LAUNCH(lstm_bwd_step_kernel, grid, dim3(64 * SK_WAVES), 0, ST(stream), a);
+  DVAE_LAUNCH_CHECK("lstm_bwd_step2");
   return 0;
 }
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     'dvae_lstm_step_bwd_pointwise_f32': (I, [P, L, P, L, P, P, L, P, L, P, P, L, L, L, P]),
     'dvae_skinny_gemm_nt_f32': (I, [P, L, P, L, P, L, L, L, L, I, P]),
     'dvae_lstm_bwd_step_f32': (I, [P, L, P, L, P, L, P, L, P, P, L, P, L, P, P, L, L, L, L, P]),
+    'dvae_lstm_bwd_step2_f32': (I, [P, L, P, L, L, P, L, P, L, L, P, L, P, L, P, P, L, P, L, P, P, L, L, L, P]),
     'dvae_lstm_seq_supported': (I, [L, L, L, L]),
     'dvae_lstm_seq_ws_floats': (L, [L, L, L]),
     'dvae_lstm_seq_fwd_f32': (I, [L] + [POINTER(c_void_p)] * 5 + [L, POINTER(c_void_p), L, POINTER(c_void_p),

@@ -560,7 +560,30 @@ class LSTMDecoder(torch.autograd.Function):
                                    dh_ext=dhs[0, 1:], dgates=dg[0, 1:], dh_init=dhs[0, 0], dc_init=dcbuf[0][1])],
                              T - 1, B, H, accumulate_dh_init=True)
             ops.lstm_step_bwd_pointwise(dhs[0, 0], dcbuf[0][1], gates[0, 0], c0[:, :H], cs[0, 0], dg[0, 0], dc0[:, :H])
-        for t in ((0,) if seq else range(T - 1, -1, -1)):
+        stacked = L >= 2
+        if stacked:
+            # Stacked decoder: walk the cells (t, l) from the last one back.  A hidden state h_{l,t} receives at
+            # most two products -- the input path of the layer above at the same step (for the top layer: of
+            # layer 0 at the next step, which it feeds) and its own layer's recurrent path from the next step --
+            # so one launch per cell adds both and goes straight through the cell's pointwise backward.
+            ops.lstm_step_bwd_pointwise(dhs[L - 1, T - 1], None, gates[L - 1, T - 1],
+                                        c0[:, (L - 1) * H:] if T == 1 else cs[L - 1, T - 2], cs[L - 1, T - 1],
+                                        dg[L - 1, T - 1], dc0[:, (L - 1) * H:] if T == 1 else dcbuf[L - 1][(T - 1) & 1])
+            for t in range(T - 1, -1, -1):
+                for l in range(L - 1, -1, -1):
+                    if t == T - 1 and l == L - 1:
+                        continue
+                    first = (dg[l + 1, t], w_ih_t[l + 1]) if l < L - 1 else (dg[0, t + 1], w_ih_t[0])
+                    second = (dg[l, t + 1], w_hh_t[l]) if t < T - 1 else (None, None)
+                    ops.lstm_bwd_step2(first[0], first[1], second[0], second[1], dhs[l, t],
+                                       None if t == T - 1 else dcbuf[l][(t + 1) & 1], gates[l, t],
+                                       c0[:, l * H:(l + 1) * H] if t == 0 else cs[l, t - 1], cs[l, t], dg[l, t],
+                                       dc0[:, l * H:(l + 1) * H] if t == 0 else dcbuf[l][t & 1])
+            # what reaches the initial states and the learned first input
+            for l in range(L):
+                ops.skinny_gemm_nt(dg[l, 0], w_hh_t[l], dh0[:, l * H:(l + 1) * H], False)
+            ops.skinny_gemm_nt(dg[0, 0], w_ih_t[0], dx0, False)
+        for t in (() if stacked else (0,) if seq else range(T - 1, -1, -1)):
             for l in range(L - 1, -1, -1):
                 w_ih, w_hh = w_ih_t[l], w_hh_t[l]
                 c_prev = c0[:, l * H:(l + 1) * H] if t == 0 else cs[l, t - 1]

@@ -602,6 +602,25 @@ def lstm_bwd_step(dg_t, wt, dh_prev, dc, gates, c_prev, c, dgates, dc_prev):
                                      _p(dc_prev), ld(dc_prev), B, H, K, _stream()), 'lstm_bwd_step')
 
 
+def lstm_bwd_step2(dg_a, wt_a, dg_b, wt_b, dh_prev, dc, gates, c_prev, c, dgates, dc_prev):
+    """dh_prev += dg_a @ wt_a^T + dg_b @ wt_b^T (the second pair may be None), then the pointwise backward of the
+    step dh_prev belongs to (arguments as in lstm_step_bwd_pointwise, for that step)."""
+    _chk2(dg_a, wt_a, dg_b, wt_b, dh_prev, dc, gates, c_prev, c, dgates, dc_prev)
+    B, Ka = dg_a.shape
+    H = wt_a.shape[0]
+    assert wt_a.shape[1] == Ka and dh_prev.shape == (B, H) and gates.is_contiguous() and dgates.is_contiguous()
+    assert dg_a.stride(1) == 1 and wt_a.stride(1) == 1 and dh_prev.stride(1) == 1
+    Kb = 0
+    if dg_b is not None:
+        Kb = dg_b.shape[1]
+        assert dg_b.shape[0] == B and wt_b.shape == (H, Kb) and dg_b.stride(1) == 1 and wt_b.stride(1) == 1
+    ld = lambda t: 0 if t is None else t.stride(0)
+    check(lib.dvae_lstm_bwd_step2_f32(_p(dg_a), dg_a.stride(0), _p(wt_a), wt_a.stride(0), Ka, _p(dg_b), ld(dg_b),
+                                      _p(wt_b), ld(wt_b), Kb, _p(dh_prev), dh_prev.stride(0), _p(dc), ld(dc),
+                                      _p(gates), _p(c_prev), ld(c_prev), _p(c), ld(c), _p(dgates), _p(dc_prev),
+                                      ld(dc_prev), B, H, _stream()), 'lstm_bwd_step2')
+
+
 def skinny_gemm_nt(a: Tensor, wt: Tensor, out: Tensor, accumulate: bool):
     """out[B,N] (+)= a[B,K] @ wt[N,K]^T; rows of a, wt and out may be strided (unit stride inside a row)."""
     _chk2(a, wt, out)

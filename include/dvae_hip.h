@@ -322,6 +322,15 @@ int dvae_lstm_bwd_step_f32(const float* dg_t, int64_t ld_dg, const float* wt, in
                            const float* c_prev, int64_t ld_cprev, const float* c, int64_t ld_c,
                            float* dgates, float* dc_prev, int64_t ld_dcprev, int64_t B, int64_t H,
                            int64_t K, dvae_stream_t stream);
+
+/* the same step for a stacked decoder, where two gradients reach one hidden state (recurrent path of the layer's
+ * next step and input path of the layer above, or of layer 0's next step for the top layer):
+ * dh_prev += dg_a * wt_a^T + dg_b * wt_b^T (dg_b / wt_b may be NULL), then the pointwise backward as above. */
+int dvae_lstm_bwd_step2_f32(const float* dg_a, int64_t ld_dga, const float* wt_a, int64_t ld_wta, int64_t Ka,
+                            const float* dg_b, int64_t ld_dgb, const float* wt_b, int64_t ld_wtb, int64_t Kb,
+                            float* dh_prev, int64_t ld_dh, const float* dc, int64_t ld_dc, const float* gates,
+                            const float* c_prev, int64_t ld_cprev, const float* c, int64_t ld_c, float* dgates,
+                            float* dc_prev, int64_t ld_dcprev, int64_t B, int64_t H, dvae_stream_t stream);
 /* Skinny GEMM of the recurrence's backward step, dh_{t-1} (+)= dG_t * W with W handed over transposed:
  * out[B,N] (+)= a[B,K] * wt[N,K]^T, every row with its own stride (floats).  Latency-oriented: 16x16
  * output tiles, K split over the waves of a workgroup, operands loaded straight into MFMA registers.
