@@ -6,9 +6,12 @@
 // fragments straight from memory (L2 resident: weights and one step's state) into the register layout
 // of v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 -- all loads of a wave are in flight at once, no
 // staging through LDS, one barrier.  The partial tiles are summed through LDS and the sigmoid/tanh
-// cell update (forward) or the accumulation into dh (backward) happens in the same kernel.  Steps are
-// separate launches on one stream (captured into a graph by the caller): on this chip a kernel
-// boundary is cheaper than a grid-wide barrier inside a persistent launch.
+// cell update (forward) or the accumulation into dh (backward) happens in the same kernel.  These
+// per-step kernels serve stacked decoders and shapes the one-launch kernels do not admit.
+//
+// Whole recurrences (second half of this file) run as ONE launch where every workgroup can be resident:
+// no grid-wide barrier -- only the H/8 workgroups that serve one group of 32 batch rows hand data to each
+// other, through 16-byte write-through stores, one arrival counter per group and L1-bypassing loads.
 #include "common.h"
 #include "../../include/dvae_hip.h"
 
