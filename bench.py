@@ -382,9 +382,14 @@ def main():
                  'gflop_per_clip': gf[1 if args.mode == 'train' else 0]}
     if rank == 0 and world == 1 and not args.no_kernel_table:
         step = train_step if args.mode == 'train' else infer_step      # kernels are timed on eager launches
+        # ... of one stream: with the weight gradients on their second stream a launch's events would also
+        # time the kernels it shares the chip with
+        from hipvae import functional as _fn
+        off_path, _fn.USE_OFF_PATH = _fn.USE_OFF_PATH, False
         step(0)                      # untimed: the eager path's buffers come out of the allocator's cache afterwards
         rows = trace_steps(step, 5, peak_tflops)
-        top = rows[0]
+        _fn.USE_OFF_PATH = off_path
+        top = next((r for r in rows if r['bound'] is not None), rows[0])
         traffic, traffic_src = pmc_traffic(top['kernel'])
         result['roofline'] = {'kernel': top['kernel'], 'bound': top['bound'], 'achieved': top['achieved'],
                               'peak': top['peak'], 'unit': top['unit'], 'frac': top['frac'], 'traffic': traffic,

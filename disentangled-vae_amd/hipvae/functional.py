@@ -50,6 +50,51 @@ def _bn_affine(stats, nparts, M, gamma, beta, bn: BNState, training: bool):
     return sc, sh, None, None
 
 
+# DVAE_OFF_PATH=1: weight gradients on a second stream beside the chain of data gradients.  Off by default: as
+# parallel branches of the captured step they made it slower on MI355X (batch 32: 3.95 against 3.55 ms, batch
+# 256: 13.8 against 13.4 ms -- every fork/join is a cross-queue dependency that costs more than the overlap buys).
+USE_OFF_PATH = os.environ.get('DVAE_OFF_PATH', '0') == '1'
+_OFF_STREAMS = {}
+
+
+class _OffPath:
+    """Inside one backward node: work whose result only the optimiser needs (weight gradients, their slab
+    reductions and re-orderings) is issued on a second stream, so that it runs beside the chain of data
+    gradients instead of in it (under graph capture: a parallel branch).  The node joins before it returns, so
+    callers see finished gradients on their own stream.  Such work takes its scratch from its own slot, and
+    every tensor it reads is kept referenced until the join (the allocator knows nothing of the second stream).
+    """
+
+    def __init__(self, like: Tensor, enabled: bool = True):
+        self.main = torch.cuda.current_stream(like.device)
+        self.side = None
+        if enabled and USE_OFF_PATH:
+            key = like.device.index if like.device.index is not None else torch.cuda.current_device()
+            if key not in _OFF_STREAMS:
+                _OFF_STREAMS[key] = torch.cuda.Stream(device=like.device)
+            self.side = _OFF_STREAMS[key]
+        self.keep = []
+        self.forked = False
+
+    def run(self, fn, *reads):
+        """fn() on the second stream, ordered behind everything issued on the main stream so far"""
+        if self.side is None:
+            return fn()
+        self.side.wait_stream(self.main)
+        self.forked = True
+        self.keep.extend(reads)
+        with torch.cuda.stream(self.side), ops.workspace_slot('off_path'):
+            out = fn()
+        self.keep.append(out)
+        return out
+
+    def join(self):
+        if self.forked:
+            self.main.wait_stream(self.side)
+        self.keep = []
+        self.forked = False
+
+
 # =================================================================================================
 def _fuse_bn_stats(channels: int) -> bool:
     """Whether the data-gradient kernel that produces a gradient with `channels` channels should also
@@ -108,10 +153,11 @@ class EncoderCNN(torch.autograd.Function):
         ys, conv_w = saved[4:4 + L], saved[4 + L:4 + 2 * L]
         affs = ctx.affs
         F_out, C, S = ctx.fc_shape
+        off = _OffPath(dfeat)
         dpre = dfeat.contiguous().clone()
         d_fc_b = ops.bias_act_bwd(dpre, feat, ops.ACT_LRELU, True)
-        d_wperm = ops.gemm_tn(dpre, u_flat)                       # [F, S*C]
-        d_fc_w = ops.permute3(d_wperm, (F_out, S, C), (0, 2, 1)).view(F_out, C * S)
+        d_fc_w = off.run(lambda: ops.permute3(ops.gemm_tn(dpre, u_flat), (F_out, S, C), (0, 2, 1)).view(F_out, C * S),
+                         dpre)                                   # via [F, S*C]
         du = ops.gemm_nn(dpre, w_perm).view(ys[-1].shape)        # grad wrt post-activation of last conv
         d_conv, d_gamma, d_beta = [None] * L, [None] * L, [None] * L
         parts = None                      # BatchNorm-backward statistics reduced by the producer of du
@@ -124,7 +170,8 @@ class EncoderCNN(torch.autograd.Function):
                 if parts is None:
                     parts = ops.bn_bwd_reduce(du, ys[0], affs[0])
                 d_gamma[0], d_beta[0], ca, cb = ops.bn_bwd_coeffs(parts, affs[0], M)
-                d_conv[0] = ops.conv4s2_wgrad_bnp(du, ys[0], affs[0], ca, cb, x)
+                d_conv[0] = off.run(lambda du=du, ca=ca, cb=cb: ops.conv4s2_wgrad_bnp(du, ys[0], affs[0], ca, cb, x),
+                                    du, ca, cb)
                 continue
             if (l > 0 and _fuse_bn_stats(ys[l - 1].shape[-1])
                     and ops.deconv4s2_bnin_supported(du, conv_w[l].shape[1])):
@@ -134,13 +181,15 @@ class EncoderCNN(torch.autograd.Function):
                 wpd = ops.pack_deconv_w(conv_w[l])
                 du, parts, dy = ops.deconv4s2_dgrad_bnstat_bnin(du, ys[l], affs[l], ca, cb, wpd, ys[l - 1], affs[l - 1])
                 psc, psh = affs[l - 1][0], affs[l - 1][1]
-                d_conv[l] = ops.conv4s2_wgrad(dy, None, None, ops.ACT_NONE, ys[l - 1], psc, psh, ops.ACT_LRELU)
+                d_conv[l] = off.run(lambda dy=dy, l=l, psc=psc, psh=psh: ops.conv4s2_wgrad(
+                    dy, None, None, ops.ACT_NONE, ys[l - 1], psc, psh, ops.ACT_LRELU), dy)
                 continue
             d_gamma[l], d_beta[l] = ops.bn_bwd(du, ys[l], sc, sh, mean, invstd, ctx.gammas[l], parts)
             dy = du                                              # now dL/d(raw conv output)
             if l > 0:
                 psc, psh = affs[l - 1][0], affs[l - 1][1]
-                d_conv[l] = ops.conv4s2_wgrad(dy, None, None, ops.ACT_NONE, ys[l - 1], psc, psh, ops.ACT_LRELU)
+                d_conv[l] = off.run(lambda dy=dy, l=l, psc=psc, psh=psh: ops.conv4s2_wgrad(
+                    dy, None, None, ops.ACT_NONE, ys[l - 1], psc, psh, ops.ACT_LRELU), dy)
                 wpd = ops.pack_deconv_w(conv_w[l])
                 if _fuse_bn_stats(ys[l - 1].shape[-1]):
                     du, parts = ops.deconv4s2_dgrad_bnstat(dy, wpd, ys[l - 1], affs[l - 1])
@@ -148,6 +197,7 @@ class EncoderCNN(torch.autograd.Function):
                     (du, _, _), parts = ops.deconv4s2_fwd(dy, None, None, ops.ACT_NONE, wpd, False), None
             else:
                 d_conv[0] = ops.conv4s2_wgrad(dy, None, None, ops.ACT_NONE, x, None, None, ops.ACT_NONE)
+        off.join()
         return (None, None, None, d_fc_w, d_fc_b, *d_conv, *d_gamma, *d_beta)
 
 
@@ -207,6 +257,7 @@ class DecoderCNN(torch.autograd.Function):
         affs = ctx.affs
         C0, S, Kin = ctx.dims
         N = feat.shape[0]
+        off = _OffPath(drecon)
         dlogit, d_final_b = ops.sigmoid_bwd(drecon.contiguous(), recon)
         Ho, Wo = recon.shape[2], recon.shape[3]
         dlogit4 = dlogit.view(N, Ho, Wo, 1)
@@ -215,7 +266,7 @@ class DecoderCNN(torch.autograd.Function):
             xin, xsc, xsh, xact = ys[-1], affs[-1][0], affs[-1][1], ops.ACT_LRELU
         else:
             xin, xsc, xsh, xact = h0.view(N, 4, 4, C0), None, None, ops.ACT_NONE
-        d_final_w = ops.conv4s2_wgrad(xin, xsc, xsh, xact, dlogit4, None, None, ops.ACT_NONE)
+        d_final_w = off.run(lambda: ops.conv4s2_wgrad(xin, xsc, xsh, xact, dlogit4, None, None, ops.ACT_NONE), dlogit)
         # the [Cin][1][4][4] weight is already the packed [Cout_c=Cin][4][4][Cin_c=1] conv layout; every
         # data-gradient kernel also reduces the BatchNorm-backward statistics of the layer below it
         parts = None
@@ -237,7 +288,8 @@ class DecoderCNN(torch.autograd.Function):
                 # it and hands the finished dL/dy to the weight gradient: no elementwise pass
                 d_gamma[l], d_beta[l], ca, cb = ops.bn_bwd_coeffs(parts, affs[l], du.numel() // du.shape[-1])
                 du, parts, dy = ops.conv4s2_dgrad_bnstat_bnin(du, ys[l], affs[l], ca, cb, wp, ys[l - 1], affs[l - 1])
-                d_dec[l] = ops.conv4s2_wgrad(pin, psc, psh, pact, dy, None, None, ops.ACT_NONE)
+                d_dec[l] = off.run(lambda dy=dy, pin=pin, psc=psc, psh=psh, pact=pact: ops.conv4s2_wgrad(
+                    pin, psc, psh, pact, dy, None, None, ops.ACT_NONE), dy)
                 continue
             if parts is not None and ops.conv4s2_wgrad_bnq_supported(pin, du.shape[-1]):
                 # here it is the weight-gradient kernel that takes du through the BatchNorm backward as it
@@ -247,17 +299,19 @@ class DecoderCNN(torch.autograd.Function):
             else:
                 d_gamma[l], d_beta[l] = ops.bn_bwd(du, ys[l], sc, sh, mean, invstd, ctx.gammas[l], parts)
                 dy = du
-                d_dec[l] = ops.conv4s2_wgrad(pin, psc, psh, pact, dy, None, None, ops.ACT_NONE)
+                d_dec[l] = off.run(lambda dy=dy, pin=pin, psc=psc, psh=psh, pact=pact: ops.conv4s2_wgrad(
+                    pin, psc, psh, pact, dy, None, None, ops.ACT_NONE), dy)
             if l > 0 and _fuse_bn_stats(ys[l - 1].shape[-1]):
                 du, parts = ops.conv4s2_dgrad_bnstat(dy, wp, ys[l - 1], affs[l - 1])
             else:
                 (du, _, _), parts = ops.conv4s2_fwd(dy, None, None, ops.ACT_NONE, wp, False), None
         dpre = du.view(N, S * C0)                  # grad wrt h0 (post-LeakyReLU), freshly allocated
         d_bperm = ops.bias_act_bwd(dpre, h0, ops.ACT_LRELU, True)
-        d_wperm = ops.gemm_tn(dpre, feat)          # [S*C0, Kin]
-        d_fc_w = ops.permute3(d_wperm, (S, C0, Kin), (1, 0, 2)).view(C0 * S, Kin)
+        d_fc_w = off.run(lambda: ops.permute3(ops.gemm_tn(dpre, feat), (S, C0, Kin), (1, 0, 2)).view(C0 * S, Kin),
+                         dpre, du)                 # via [S*C0, Kin]
         d_fc_b = ops.permute3(d_bperm, (S, C0, 1), (1, 0, 2)).view(C0 * S)
         dfeat = ops.gemm_nn(dpre, w_perm)
+        off.join()
         return (dfeat, None, None, d_fc_w, d_fc_b, d_final_w, d_final_b, *d_dec, *d_gamma, *d_beta)
 
 
@@ -284,8 +338,10 @@ class Linear(torch.autograd.Function):
         if ctx.act != ops.ACT_NONE:
             d = d.clone()
         db = ops.bias_act_bwd(d, out, ctx.act, ctx.has_bias)
-        dw = ops.gemm_tn(d, x2) if ctx.needs_input_grad[1] else None
+        off = _OffPath(d, ctx.needs_input_grad[0] and ctx.needs_input_grad[1])
+        dw = off.run(lambda: ops.gemm_tn(d, x2), d) if ctx.needs_input_grad[1] else None
         dx = ops.gemm_nn(d, w.contiguous()).view(ctx.in_shape) if ctx.needs_input_grad[0] else None
+        off.join()
         return dx, dw, db, None
 
 

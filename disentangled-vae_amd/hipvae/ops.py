@@ -37,11 +37,28 @@ def _p(t: Optional[Tensor]):
 
 _WS = {}
 _WS_RETIRED = []
+_WS_SLOT = ['main']
 
 
-def workspace(nfloats: int, device, slot: str = 'main') -> Tensor:
+class workspace_slot:
+    """Ops launched inside the block take their scratch from the named slot instead of 'main': work that runs
+    on a second stream beside the main chain must not share the main chain's scratch."""
+
+    def __init__(self, slot: str):
+        self.slot = slot
+
+    def __enter__(self):
+        _WS_SLOT.append(self.slot)
+        return self
+
+    def __exit__(self, *exc):
+        _WS_SLOT.pop()
+        return False
+
+
+def workspace(nfloats: int, device, slot: Optional[str] = None) -> Tensor:
     """Grow-only scratch buffer per (device, slot); contents are only valid within one op."""
-    key = (torch.device(device).index, slot)
+    key = (torch.device(device).index, slot if slot is not None else _WS_SLOT[-1])
     buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
         if buf is not None:
