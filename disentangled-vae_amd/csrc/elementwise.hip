@@ -513,6 +513,175 @@ extern "C" int dvae_kl_bwd_f32(const float* mu, const float* logvar, const float
 }
 
 // ------------------------------------------------------------------------------------------------
+// The objective in two launches: the pass over the clip (recon_loss_fwd_kernel: per-workgroup partial sums
+// of the reconstruction and temporal terms), then ONE workgroup that finishes everything small -- sums the
+// partials, computes the KL terms of one or two latents, applies the weights and writes every entry of the
+// loss dictionary.  out layout 0 (one latent, 7 floats): total, recon per pixel, recon, temporal, kl, kl raw,
+// kl per dim.  Layout 1 (two latents, 12 floats): total, kl, recon per pixel, recon, temporal, content kl
+// (mean, raw, per dim), motion kl (same), independence.
+// ------------------------------------------------------------------------------------------------
+struct LossFinishArgs {
+  const double* partials; int nparts;
+  double B, T, P;
+  const float* mu[2]; const float* lv[2]; int64_t D[2];
+  float beta[2];
+  int nkl;
+  float free_bits, temporal_weight, indep_weight;
+  const float* indep;        // value of the independence term (device scalar) or nullptr
+  int layout;
+  float* out;
+  float* total_out;          // the total once more, as a tensor of its own (nullptr: not wanted)
+};
+
+__global__ void __launch_bounds__(1024) vae_loss_finish_kernel(LossFinishArgs a) {
+  __shared__ double red[6][16];
+  const int wave = threadIdx.x >> 6;
+  double s_rec = 0.0, s_tmp = 0.0;
+  for (int i = threadIdx.x; i < a.nparts; i += 1024) {
+    s_rec += a.partials[2 * i];
+    s_tmp += a.partials[2 * i + 1];
+  }
+  double kf[2] = {0.0, 0.0}, kr[2] = {0.0, 0.0};
+  const int64_t rows = (int64_t)a.B;
+  for (int p = 0; p < a.nkl; ++p) {
+    const int64_t n = rows * a.D[p];
+    double s_floor[4] = {0.0, 0.0, 0.0, 0.0}, s_raw[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i0 = threadIdx.x; i0 < n; i0 += 4096) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t i = i0 + 1024 * u;
+        if (i < n) {
+          const float m = a.mu[p][i], lv = a.lv[p][i];
+          const float kl = -0.5f * (1.f + lv - m * m - expf(lv));
+          s_raw[u] += (double)kl;
+          s_floor[u] += (double)((a.free_bits > 0.f) ? fmaxf(kl, a.free_bits) : kl);
+        }
+      }
+    }
+    kf[p] = (s_floor[0] + s_floor[1]) + (s_floor[2] + s_floor[3]);
+    kr[p] = (s_raw[0] + s_raw[1]) + (s_raw[2] + s_raw[3]);
+  }
+  const double v[6] = {s_rec, s_tmp, kf[0], kr[0], kf[1], kr[1]};
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const double w = wave_sum(v[q]);
+    if ((threadIdx.x & 63) == 0) red[q][wave] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[6];
+    for (int q = 0; q < 6; ++q) {
+      double acc = 0.0;
+      for (int w = 0; w < 16; ++w) acc += red[q][w];
+      t[q] = acc;
+    }
+    const float per_pixel = (float)(t[0] / (a.B * a.T * a.P));
+    const float rec = per_pixel * (float)(a.T * a.P);
+    const float tmp = a.T > 1 ? (float)(t[1] / (a.B * (a.T - 1) * a.P)) * (float)((a.T - 1) * a.P) : 0.f;
+    float kl_mean[2] = {0.f, 0.f}, kl_raw[2] = {0.f, 0.f}, kl_dim[2] = {0.f, 0.f};
+    for (int p = 0; p < a.nkl; ++p) {
+      kl_mean[p] = (float)(t[2 + 2 * p] / a.B);
+      kl_raw[p] = (float)(t[3 + 2 * p] / a.B);
+      kl_dim[p] = (float)(t[2 + 2 * p] / (a.B * (double)a.D[p]));
+    }
+    float total;
+    if (a.layout == 0) {
+      float s = 0.f;
+      s += 1.f * rec;
+      s += a.beta[0] * kl_mean[0];
+      s += a.temporal_weight * tmp;
+      total = s;
+      a.out[0] = total; a.out[1] = per_pixel; a.out[2] = rec; a.out[3] = tmp;
+      a.out[4] = kl_mean[0]; a.out[5] = kl_raw[0]; a.out[6] = kl_dim[0];
+    } else {
+      float kl = 0.f;
+      kl += a.beta[0] * kl_mean[0];
+      kl += a.beta[1] * kl_mean[1];
+      const float ind = a.indep ? a.indep[0] : 0.f;
+      float s = 0.f;
+      s += 1.f * rec;
+      s += 1.f * kl;
+      s += a.temporal_weight * tmp;
+      s += a.indep_weight * ind;
+      total = s;
+      a.out[0] = total; a.out[1] = kl; a.out[2] = per_pixel; a.out[3] = rec; a.out[4] = tmp;
+      a.out[5] = kl_mean[0]; a.out[6] = kl_raw[0]; a.out[7] = kl_dim[0];
+      a.out[8] = kl_mean[1]; a.out[9] = kl_raw[1]; a.out[10] = kl_dim[1];
+      a.out[11] = ind;
+    }
+    if (a.total_out) a.total_out[0] = total;
+  }
+}
+
+extern "C" int dvae_vae_loss_fwd_f32(const float* recon, const float* target, int64_t B, int64_t T, int64_t P, int kind,
+                                     int with_temporal, const float* mu0, const float* logvar0, int64_t D0,
+                                     float beta0, const float* mu1, const float* logvar1, int64_t D1, float beta1,
+                                     float free_bits, float temporal_weight, const float* indep, float indep_weight,
+                                     float* out, float* total_out, float* ws, dvae_stream_t stream) {
+  DVAE_REQUIRE(B > 0 && T >= 1 && P > 0 && P % 4 == 0, "vae_loss_fwd: need P%%4==0");
+  DVAE_REQUIRE(kind == 0 || kind == 1, "vae_loss_fwd: kind must be 0 (mse) or 1 (bce)");
+  DVAE_REQUIRE(recon && target && mu0 && logvar0 && out && ws && D0 > 0, "vae_loss_fwd: null argument");
+  DVAE_REQUIRE((mu1 == nullptr) == (logvar1 == nullptr) && (mu1 == nullptr || D1 > 0), "vae_loss_fwd: the second latent needs mu, logvar and its width");
+  DVAE_REQUIRE(((uintptr_t)ws & 7) == 0, "vae_loss_fwd: workspace must be 8-byte aligned");
+  const int nb = recon_blocks(B, P);
+  DVAE_WORK(8.0 * (double)B * T * P, DVAE_UNIT_BYTE);                      // recon and target, once each
+  DVAE_LAUNCH(recon_loss_fwd_kernel, dim3(nb), dim3(256), 0, ST(stream), (const float4*)recon,
+                     (const float4*)target, (double*)ws, B * (P / 4), (int)T, P / 4, kind, with_temporal);
+  DVAE_LAUNCH_CHECK("vae_loss_fwd");
+  LossFinishArgs a;
+  a.partials = (const double*)ws; a.nparts = nb;
+  a.B = (double)B; a.T = (double)T; a.P = (double)P;
+  a.mu[0] = mu0; a.lv[0] = logvar0; a.D[0] = D0; a.beta[0] = beta0;
+  a.mu[1] = mu1; a.lv[1] = logvar1; a.D[1] = mu1 ? D1 : 0; a.beta[1] = beta1;
+  a.nkl = mu1 ? 2 : 1;
+  a.free_bits = free_bits; a.temporal_weight = temporal_weight; a.indep_weight = indep_weight;
+  a.indep = indep; a.layout = mu1 ? 1 : 0; a.out = out; a.total_out = total_out;
+  DVAE_LAUNCH(vae_loss_finish_kernel, dim3(1), dim3(1024), 0, ST(stream), a);
+  DVAE_LAUNCH_CHECK("vae_loss_finish");
+  return 0;
+}
+
+// KL gradients of one or two latents in one launch (coef_i = beta_i; the 1/B of the batch mean is applied here)
+__global__ void kl_bwd2_kernel(const float* mu0, const float* lv0, float* dmu0, float* dlv0, int64_t n0, float c0,
+                               const float* mu1, const float* lv1, float* dmu1, float* dlv1, int64_t n1, float c1,
+                               const float* gscale, float free_bits) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const float* mu = mu0; const float* lvp = lv0; float* dmu = dmu0; float* dlv = dlv0; float coef = c0;
+  if (i >= n0) {
+    i -= n0;
+    if (i >= n1) return;
+    mu = mu1; lvp = lv1; dmu = dmu1; dlv = dlv1; coef = c1;
+  }
+  const float c = coef * (gscale ? gscale[0] : 1.f);
+  const float m = mu[i], lv = lvp[i];
+  const float e = expf(lv);
+  float gm = c * m, gl = c * 0.5f * (e - 1.f);
+  if (free_bits > 0.f) {
+    const float kl = -0.5f * (1.f + lv - m * m - e);
+    if (!(kl > free_bits)) {  // the floor is active: maximum() passes no gradient to kl
+      gm = 0.f;
+      gl = 0.f;
+    }
+  }
+  dmu[i] = gm;
+  dlv[i] = gl;
+}
+
+extern "C" int dvae_kl_bwd2_f32(const float* mu0, const float* logvar0, float coef0, float* dmu0, float* dlogvar0,
+                                int64_t D0, const float* mu1, const float* logvar1, float coef1, float* dmu1,
+                                float* dlogvar1, int64_t D1, const float* gscale, int64_t B, float free_bits,
+                                dvae_stream_t stream) {
+  DVAE_REQUIRE(B > 0 && D0 > 0 && mu0 && logvar0 && dmu0 && dlogvar0, "kl_bwd2: empty or null");
+  DVAE_REQUIRE(mu1 == nullptr || (logvar1 && dmu1 && dlogvar1 && D1 > 0), "kl_bwd2: the second latent is incomplete");
+  const int64_t n0 = B * D0, n1 = mu1 ? B * D1 : 0;
+  DVAE_LAUNCH(kl_bwd2_kernel, dim3((unsigned)ceil_div64(n0 + n1, 256)), dim3(256), 0, ST(stream), mu0, logvar0, dmu0,
+                     dlogvar0, n0, coef0 / (float)B, mu1, logvar1, dmu1, dlogvar1, n1, coef1 / (float)B, gscale,
+                     free_bits);
+  DVAE_LAUNCH_CHECK("kl_bwd2");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // independence term.  ws layout: corr[Dc*Dm] | mean_c[Dc] | inv_c[Dc] | mean_m[Dm] | inv_m[Dm] | part[Dc]
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -1005,8 +1174,21 @@ extern "C" int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, flo
   DVAE_REQUIRE(M > 0 && N > 0 && N % 4 == 0, "bias_act_bwd: need N%%4==0 (N=%ld)", (long)N);
   DVAE_REQUIRE(act == DVAE_ACT_NONE || act == DVAE_ACT_LRELU, "bias_act_bwd: unsupported activation %d", act);
   if (act == DVAE_ACT_NONE && dbias == nullptr) return 0;
-  const ColsumGeom g = colsum_geom(M, N);
   DVAE_WORK((act == DVAE_ACT_LRELU ? 12.0 : 4.0) * (double)M * N, DVAE_UNIT_BYTE);
+  if (M <= 64) {
+    // a handful of rows (latent heads at small batch): one launch; beyond that the two-stage form is faster.  Narrow column groups (at most 32 x 4 columns per workgroup) so that a workgroup
+    // walks the rows with as many of them side by side as its 256 threads allow, and writes the sums itself.
+    const int64_t c4 = N / 4;
+    int tx = 1;
+    while (tx < c4 && tx < 32) tx <<= 1;
+    const int ty = 256 / tx;
+    DVAE_LAUNCH(colsum_kernel<1>, dim3(1, (unsigned)ceil_div64(c4, tx)), dim3(256), 0, ST(stream), dout, out,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act,
+                       dbias ? dbias : ws, M, N, tx, ty);
+    DVAE_LAUNCH_CHECK("bias_act_bwd");
+    return 0;
+  }
+  const ColsumGeom g = colsum_geom(M, N);
   DVAE_LAUNCH(colsum_kernel<1>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), dout, out,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, ws,
                      M, N, g.tx, g.ty);

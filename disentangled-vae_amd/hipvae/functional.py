@@ -588,6 +588,7 @@ class LSTMDecoder(torch.autograd.Function):
         states = ops.permute3(hs[L - 1], (T, B, H), (1, 0, 2))         # [B, T, H]
         ctx.save_for_backward(h0, c0, init_c, hs, cs, gates, *weights)
         ctx.cfg = (B, T, L, H)
+        ctx.w_comb = w_comb if seq else None      # W_ih + W_hh once per step, for the backward launch too
         return states
 
     @staticmethod
@@ -596,8 +597,11 @@ class LSTMDecoder(torch.autograd.Function):
         saved = ctx.saved_tensors
         h0, c0, init_c, hs, cs, gates = saved[:6]
         weights = [t.contiguous() for t in saved[6:]]
-        dhs = _zeros(L, T, B, H, like=h0)
-        dhs[L - 1] = ops.permute3(dstates.contiguous(), (B, T, H), (1, 0, 2))
+        if L == 1:
+            dhs = ops.permute3(dstates.contiguous(), (B, T, H), (1, 0, 2)).view(1, T, B, H)
+        else:
+            dhs = _zeros(L, T, B, H, like=h0)
+            dhs[L - 1] = ops.permute3(dstates.contiguous(), (B, T, H), (1, 0, 2))
         dg = _empty(L, T, B, 4 * H, like=h0)
         dh0 = _empty(B, L * H, like=h0)
         dc0 = _empty(B, L * H, like=h0)
@@ -607,12 +611,13 @@ class LSTMDecoder(torch.autograd.Function):
         # for a single layer both paths of a step t > 0 end in h_{t-1}, so they share W_ih + W_hh
         w_ih_t = [weights[4 * l].t().contiguous() for l in range(L)]
         w_hh_t = [weights[4 * l + 1].t().contiguous() for l in range(L)]
-        w_comb_t = (w_ih_t[0] + w_hh_t[0]) if (L == 1 and T > 1) else None
-        fused = w_comb_t is not None      # single layer: one launch per step (product + next pointwise)
-        seq = fused and USE_SEQ_KERNELS and ops.lstm_seq_supported(1, T - 1, B, H)
+        fused = L == 1 and T > 1          # single layer: one launch per step (product + next pointwise) ...
+        seq = fused and USE_SEQ_KERNELS and ops.lstm_seq_supported(1, T - 1, B, H)   # ... or one for all of them
+        w_comb_t = (w_ih_t[0] + w_hh_t[0]) if (fused and not seq) else None
         if seq:
             # steps T-1 .. 1 in one launch (W_ih + W_hh in registers); it leaves dL/dh_0 and dL/dc_0 for step 0
-            ops.lstm_seq_bwd([dict(w_rec=weights[0] + weights[1], gates=gates[0, 1:], cseq=cs[0, 1:], c_init=cs[0, 0],
+            w_comb = ctx.w_comb if ctx.w_comb is not None else weights[0] + weights[1]
+            ops.lstm_seq_bwd([dict(w_rec=w_comb, gates=gates[0, 1:], cseq=cs[0, 1:], c_init=cs[0, 0],
                                    dh_ext=dhs[0, 1:], dgates=dg[0, 1:], dh_init=dhs[0, 0], dc_init=dcbuf[0][1])],
                              T - 1, B, H, accumulate_dh_init=True)
             ops.lstm_step_bwd_pointwise(dhs[0, 0], dcbuf[0][1], gates[0, 0], c0[:, :H], cs[0, 0], dg[0, 0], dc0[:, :H])

@@ -1,7 +1,7 @@
 """Fused loss nodes: reconstruction (MSE/BCE) + temporal stencil + KL (+ free bits) + independence.
 
-One autograd node per loss call.  Forward launches reduction kernels only and leaves every term as a
-device scalar; backward launches the gradient kernels, each reading the upstream gradient of
+One autograd node per loss call.  Forward is two launches (the pass over the clips, then one workgroup that finishes every
+term; the independence term adds its own) and leaves every term as a device scalar; backward launches the gradient kernels, each reading the upstream gradient of
 ``total_loss`` from device memory, so nothing synchronises with the host.  Only ``total_loss``
 carries gradient (the other entries are reporting values, as the reference's Trainer uses them).
 """
@@ -21,8 +21,12 @@ class LossDict(dict):
     whole step's values with one device add and read them back once per logging interval instead of
     calling .item() per entry per step."""
 
-    def __init__(self, packed: Tensor, layout: Dict[str, int], beta: float):
+    def __init__(self, packed: Tensor, layout: Dict[str, int], beta: float, total: Optional[Tensor] = None):
         super().__init__({k: packed[i] for k, i in layout.items()})
+        if total is not None:
+            # the entry that carries the gradient is a tensor of its own (same value as packed[0]): its backward
+            # then starts from the loss node directly instead of going through an indexing node's zero-fill + copy
+            self['total_loss'] = total
         self['beta'] = torch.tensor(beta)          # a CPU tensor, as in the reference
         self.packed = packed
         self.layout = layout
@@ -36,38 +40,37 @@ def _kind(name: str) -> int:
 
 class _DisentangledLoss(torch.autograd.Function):
     # values layout: 0 total, 1 kl, 2 recon_per_pixel, 3 recon_scaled, 4 temporal, 5..7 content KL
-    # (mean, raw, per-dim), 8..10 motion KL, 11 independence: every kernel writes its own slots
+    # (mean, raw, per-dim), 8..10 motion KL, 11 independence.  Two outputs: the packed values (reporting only) and
+    # the total as a tensor of its own, which is what carries the gradient.
     @staticmethod
     def forward(ctx, recon, target, mu_c, lv_c, mu_m, lv_m, z_c, z_m, beta_c, beta_m, kind, tw, iw):
         recon, target = recon.contiguous(), target.contiguous()
         mu_c, lv_c, mu_m, lv_m = [t.contiguous() for t in (mu_c, lv_c, mu_m, lv_m)]
-        vals = torch.zeros(12, dtype=torch.float32, device=recon.device)
-        ops.recon_loss_fwd(recon, target, kind, tw > 0, vals[2:5])
-        ops.kl_fwd(mu_c, lv_c, 0.0, vals[5:8])
-        ops.kl_fwd(mu_m, lv_m, 0.0, vals[8:11])
+        vals = torch.empty(12, dtype=torch.float32, device=recon.device)
+        total = torch.empty(1, dtype=torch.float32, device=recon.device)
         ws = None
         if iw > 0:
             z_c, z_m = z_c.contiguous(), z_m.contiguous()
             ws = ops.indep_fwd(z_c, z_m, vals[11:12])
-        ops.weighted_sum([vals[5:6], vals[8:9]], [beta_c, beta_m], vals[1:2])
-        ops.weighted_sum([vals[3:4], vals[1:2], vals[4:5], vals[11:12]], [1.0, 1.0, tw, iw], vals[0:1])
+        # the pass over the clips, then one workgroup for everything small (both KL terms, weights, totals)
+        ops.vae_loss_fwd(recon, target, kind, tw > 0, [(mu_c, lv_c, beta_c), (mu_m, lv_m, beta_m)], 0.0, tw,
+                         vals[11:12] if iw > 0 else None, iw, vals, total)
         ctx.save_for_backward(recon, target, mu_c, lv_c, mu_m, lv_m, z_c if iw > 0 else None,
                               z_m if iw > 0 else None, ws)
         ctx.cfg = (beta_c, beta_m, kind, tw, iw)
-        return vals
+        ctx.mark_non_differentiable(vals)
+        return vals, total.view(())
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, _gvals, g):
         recon, target, mu_c, lv_c, mu_m, lv_m, z_c, z_m, ws = ctx.saved_tensors
         beta_c, beta_m, kind, tw, iw = ctx.cfg
-        gs = g.contiguous()[0:1]                                   # d/d total_loss, a device scalar
+        gs = g.reshape(1).contiguous()                             # d/d total_loss, a device scalar
         need = ctx.needs_input_grad
         drecon = ops.recon_loss_bwd(recon, target, gs, kind, tw) if need[0] else None
         dmu_c = dlv_c = dmu_m = dlv_m = dz_c = dz_m = None
-        if need[2] or need[3]:
-            dmu_c, dlv_c = ops.kl_bwd(mu_c, lv_c, gs, beta_c, 0.0)
-        if need[4] or need[5]:
-            dmu_m, dlv_m = ops.kl_bwd(mu_m, lv_m, gs, beta_m, 0.0)
+        if need[2] or need[3] or need[4] or need[5]:
+            (dmu_c, dlv_c), (dmu_m, dlv_m) = ops.kl_bwd2([(mu_c, lv_c, beta_c), (mu_m, lv_m, beta_m)], gs, 0.0)
         if iw > 0 and (need[6] or need[7]):
             dz_c, dz_m = ops.indep_bwd(z_c, z_m, ws, gs, iw)
         return (drecon, None, dmu_c, dlv_c, dmu_m, dlv_m, dz_c, dz_m, None, None, None, None, None)
@@ -81,12 +84,12 @@ def disentangled_loss(output: Dict[str, Tensor], target: Tensor, beta: float = 1
     kind = _kind(recon_loss_type)
     bc = beta_content if beta_content is not None else beta
     bm = beta_motion if beta_motion is not None else beta
-    v = _DisentangledLoss.apply(output['recon'], target, output['mu_content'], output['logvar_content'],
-                                output['mu_motion'], output['logvar_motion'], output['z_content'],
-                                output['z_motion'], float(bc), float(bm), kind, float(temporal_weight),
-                                float(independence_weight))
+    v, total = _DisentangledLoss.apply(output['recon'], target, output['mu_content'], output['logvar_content'],
+                                       output['mu_motion'], output['logvar_motion'], output['z_content'],
+                                       output['z_motion'], float(bc), float(bm), kind, float(temporal_weight),
+                                       float(independence_weight))
     return LossDict(v, {'total_loss': 0, 'recon_loss': 3, 'recon_loss_per_pixel': 2, 'kl_loss': 1,
-                        'kl_content': 5, 'kl_motion': 8, 'temporal_loss': 4, 'independence_loss': 11}, beta)
+                        'kl_content': 5, 'kl_motion': 8, 'temporal_loss': 4, 'independence_loss': 11}, beta, total)
 
 
 class _TupleLoss(torch.autograd.Function):
@@ -94,19 +97,19 @@ class _TupleLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, recon, target, mu, logvar, beta, kind, tw, free_bits):
         recon, target, mu, logvar = [t.contiguous() for t in (recon, target, mu, logvar)]
-        vals = torch.zeros(7, dtype=torch.float32, device=recon.device)
-        ops.recon_loss_fwd(recon, target, kind, tw > 0, vals[1:4])
-        ops.kl_fwd(mu, logvar, free_bits, vals[4:7])
-        ops.weighted_sum([vals[2:3], vals[4:5], vals[3:4]], [1.0, beta, tw], vals[0:1])
+        vals = torch.empty(7, dtype=torch.float32, device=recon.device)
+        total = torch.empty(1, dtype=torch.float32, device=recon.device)
+        ops.vae_loss_fwd(recon, target, kind, tw > 0, [(mu, logvar, beta)], free_bits, tw, None, 0.0, vals, total)
         ctx.save_for_backward(recon, target, mu, logvar)
         ctx.cfg = (beta, kind, tw, free_bits)
-        return vals
+        ctx.mark_non_differentiable(vals)
+        return vals, total.view(())
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, _gvals, g):
         recon, target, mu, logvar = ctx.saved_tensors
         beta, kind, tw, free_bits = ctx.cfg
-        gs = g.contiguous()[0:1]
+        gs = g.reshape(1).contiguous()
         need = ctx.needs_input_grad
         drecon = ops.recon_loss_bwd(recon, target, gs, kind, tw) if need[0] else None
         dmu = dlv = None
@@ -124,14 +127,14 @@ def _tuple_loss(recon, target, mu, logvar, beta, recon_loss_type, temporal_weigh
 def lstm_loss(recon, target, mu, logvar, beta: float = 1.0, recon_loss_type: str = 'mse',
               temporal_weight: float = 0.0, free_bits: float = 0.0, use_free_bits: bool = False):
     """Same signature and keys as models/lstm_vae.py:167-220."""
-    v = _tuple_loss(recon, target, mu, logvar, beta, recon_loss_type, temporal_weight, free_bits, use_free_bits)
+    v, total = _tuple_loss(recon, target, mu, logvar, beta, recon_loss_type, temporal_weight, free_bits, use_free_bits)
     return LossDict(v, {'total_loss': 0, 'recon_loss': 2, 'recon_loss_per_pixel': 1, 'kl_loss': 4,
-                        'kl_loss_raw': 5, 'kl_per_dim': 6, 'temporal_loss': 3}, beta)
+                        'kl_loss_raw': 5, 'kl_per_dim': 6, 'temporal_loss': 3}, beta, total)
 
 
 def baseline_loss(recon, target, mu, logvar, beta: float = 1.0, recon_loss_type: str = 'mse',
                   free_bits: float = 0.0, use_free_bits: bool = False):
     """Same signature and keys as models/baseline_vae.py:208-252."""
-    v = _tuple_loss(recon, target, mu, logvar, beta, recon_loss_type, 0.0, free_bits, use_free_bits)
+    v, total = _tuple_loss(recon, target, mu, logvar, beta, recon_loss_type, 0.0, free_bits, use_free_bits)
     return LossDict(v, {'total_loss': 0, 'recon_loss': 2, 'recon_loss_per_pixel': 1, 'kl_loss': 4,
-                        'kl_loss_raw': 5, 'kl_per_dim': 6}, beta)
+                        'kl_loss_raw': 5, 'kl_per_dim': 6}, beta, total)
