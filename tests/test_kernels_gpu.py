@@ -476,6 +476,30 @@ def test_lstm_bwd_step_is_product_then_pointwise(ops, B, H):
         assert torch.equal(got_dh, ref_dh) and torch.equal(got_dg, ref_dg) and torch.equal(got_dc, ref_dc)
 
 
+@pytest.mark.parametrize('B,H,second', [(6, 32, True), (37, 24, True), (32, 256, True), (32, 256, False)])
+def test_lstm_bwd_step2_adds_both_products(ops, B, H, second):
+    """The stacked decoder's backward cell: two products onto one hidden-state gradient, then the pointwise
+    backward, against the separate kernels."""
+    dg_a, dg_b = dev(rnd(B, 4 * H, seed=176)), dev(rnd(B, 4 * H, seed=177))
+    wt_a = dev(rnd(4 * H, H, seed=178, scale=0.2)).t().contiguous()
+    wt_b = dev(rnd(4 * H, H, seed=179, scale=0.2)).t().contiguous()
+    dh0, dc = rnd(B, H, seed=180), dev(rnd(B, H, seed=181))
+    gates = dev(torch.sigmoid(rnd(B, 4 * H, seed=182)))
+    c_prev, c = dev(rnd(B, H, seed=183)), dev(rnd(B, H, seed=184))
+    ref_dh = dev(dh0)
+    ops.skinny_gemm_nt(dg_a, wt_a, ref_dh, True)
+    if second:
+        ops.skinny_gemm_nt(dg_b, wt_b, ref_dh, True)
+    ref_dg, ref_dc = torch.empty(B, 4 * H, device='cuda'), torch.empty(B, H, device='cuda')
+    ops.lstm_step_bwd_pointwise(ref_dh, dc, gates, c_prev, c, ref_dg, ref_dc)
+    got_dh = dev(dh0)
+    got_dg, got_dc = torch.empty(B, 4 * H, device='cuda'), torch.empty(B, H, device='cuda')
+    ops.lstm_bwd_step2(dg_a, wt_a, dg_b if second else None, wt_b if second else None, got_dh, dc, gates, c_prev, c,
+                       got_dg, got_dc)
+    # one sum over both products instead of two roundings onto dh: equal to rounding, not bit for bit
+    assert rel_err(got_dh, ref_dh) < 2e-6 and rel_err(got_dg, ref_dg) < 2e-6 and rel_err(got_dc, ref_dc) < 2e-6
+
+
 @pytest.mark.parametrize('B,N,K', [(32, 256, 1024), (256, 256, 1024), (70, 36, 132), (1, 4, 4), (17, 3, 2052)])
 def test_skinny_gemm(ops, B, N, K):
     a, w = rnd(B, K, seed=74), rnd(K, N, seed=75)
@@ -619,6 +643,59 @@ def test_lstm_seq_rejects_what_cannot_be_resident(ops):
     assert not ops.lstm_seq_supported(2, 19, 512, 256)           # 1024 workgroups
     assert not ops.lstm_seq_supported(1, 19, 32, 32)             # hidden size without a kernel
     assert ops.lstm_seq_supported(2, 19, 256, 256) and ops.lstm_seq_supported(1, 19, 256, 512)
+
+
+@pytest.mark.parametrize('kind,tw,free_bits', [('bce', 0.05, 0.0), ('mse', 0.0, 0.0), ('mse', 0.1, 0.5)])
+def test_vae_loss_in_two_launches(ops, kind, tw, free_bits):
+    """dvae_vae_loss_fwd_f32 / dvae_kl_bwd2_f32 against the fp64 terms of the oracle: one latent (with the
+    free-bits floor) and two latents (with an independence value handed in)."""
+    B, T, D0, D1 = 5, 4, 16, 24
+    g = torch.Generator().manual_seed(12)
+    target = (torch.rand(B, T, 1, 64, 64, generator=g) > 0.9).float() * torch.rand(B, T, 1, 64, 64, generator=g)
+    recon = torch.sigmoid(torch.randn(B, T, 1, 64, 64, generator=g) * 3)
+    mu0, lv0 = rnd(B, D0, seed=13), rnd(B, D0, seed=14, scale=0.5)
+    mu1, lv1 = rnd(B, D1, seed=15), rnd(B, D1, seed=16, scale=0.5)
+    r64, t64 = recon.double(), target.double()
+    rec_pp = O.recon_term(r64, t64, kind)
+    rec = rec_pp * (T * 4096)
+    tmp = O.temporal_term(r64, t64)
+
+    def kl_terms(mu, lv, fb):
+        per = -0.5 * (1 + lv - mu ** 2 - lv.exp())
+        floored = torch.clamp(per, min=fb) if fb > 0 else per
+        return floored.sum(1).mean(), per.sum(1).mean(), floored.mean()
+
+    knd = 0 if kind == 'mse' else 1
+    # one latent
+    out, total = torch.full((7,), -1.0, device='cuda'), torch.full((1,), -1.0, device='cuda')
+    ops.vae_loss_fwd(dev(recon), dev(target), knd, tw > 0, [(dev(mu0), dev(lv0), 0.4)], free_bits, tw, None, 0.0,
+                     out, total)
+    k, kraw, kdim = kl_terms(mu0, lv0, free_bits)
+    ref = [rec + 0.4 * k + tw * (tmp if tw > 0 else 0.0), rec_pp, rec, tmp if tw > 0 else torch.tensor(0.0), k, kraw, kdim]
+    o = out.cpu().double()
+    for i, rv in enumerate(ref):
+        assert abs(o[i] - float(rv)) <= 2e-6 * max(abs(float(rv)), 1e-3), (i, float(o[i]), float(rv))
+    assert total.item() == out[0].item()
+    # two latents, independence value handed in
+    ind = torch.tensor([0.37], device='cuda')
+    out, total = torch.full((12,), -1.0, device='cuda'), torch.full((1,), -1.0, device='cuda')
+    ops.vae_loss_fwd(dev(recon), dev(target), knd, tw > 0, [(dev(mu0), dev(lv0), 0.4), (dev(mu1), dev(lv1), 4.0)], 0.0,
+                     tw, ind, 0.02, out, total)
+    k0, k0raw, k0dim = kl_terms(mu0, lv0, 0.0)
+    k1, k1raw, k1dim = kl_terms(mu1, lv1, 0.0)
+    klsum = 0.4 * k0 + 4.0 * k1
+    tt = tmp if tw > 0 else torch.tensor(0.0)
+    ref = [rec + klsum + tw * tt + 0.02 * 0.37, klsum, rec_pp, rec, tt, k0, k0raw, k0dim, k1, k1raw, k1dim, 0.37]
+    o = out.cpu().double()
+    for i, rv in enumerate(ref):
+        assert abs(o[i] - float(rv)) <= 2e-6 * max(abs(float(rv)), 1e-3), (i, float(o[i]), float(rv))
+    assert total.item() == out[0].item()
+    # both KL gradients in one launch against the single-latent kernel
+    gs = torch.tensor([0.7], device='cuda')
+    (a0, b0), (a1, b1) = ops.kl_bwd2([(dev(mu0), dev(lv0), 0.4), (dev(mu1), dev(lv1), 4.0)], gs, free_bits)
+    r0 = ops.kl_bwd(dev(mu0), dev(lv0), gs, 0.4, free_bits)
+    r1 = ops.kl_bwd(dev(mu1), dev(lv1), gs, 4.0, free_bits)
+    assert torch.equal(a0, r0[0]) and torch.equal(b0, r0[1]) and torch.equal(a1, r1[0]) and torch.equal(b1, r1[1])
 
 
 # ------------------------------------------------------------------ optimiser
