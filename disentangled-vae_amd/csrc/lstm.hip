@@ -970,3 +970,222 @@ extern "C" int dvae_lstm_seq_bwd_f32(int64_t nchains, const float* const* w_rec,
   DVAE_LAUNCH_CHECK("lstm_seq_bwd");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Stacked autoregressive decoder (two LSTM layers, models/decoders.py:110-137) in ONE launch, forward.
+//
+// Cell (t, l) computes   pre = x W_ih_l^T + h_{l,t-1} W_hh_l^T + b,   x = h_{1,t-1} for layer 0 (the top layer's
+// previous output; the learned first input at t = 0) and x = h_{0,t} for layer 1.  The cells form one chain
+// (0,0) (0,1) (1,0) (1,1) ...; partition, hand-off and residency are those of lstm_seq_fwd_kernel: a workgroup
+// owns eight hidden units of BOTH layers, keeps the four 32 x H weight slices in registers (64 per lane at
+// H = 256) and both cell states in registers, and every cell publishes its 32 x 8 block of h to the group
+// (one buffer pair per layer) behind one arrival counter that counts cells.
+// ------------------------------------------------------------------------------------------------
+#define DEC_L 2
+
+struct LstmDecArgs {
+  const float* w_ih[DEC_L]; const float* w_hh[DEC_L];     // [4H][H] each
+  const float* b_ih[DEC_L]; const float* b_hh[DEC_L];     // [4H] each
+  const float* h0; int64_t ld_h0;                         // [B][L*H]: layer l starts from columns l*H ..
+  const float* c0; int64_t ld_c0;
+  const float* init;                                      // [H] first input of layer 0, the same for every row
+  float* gates;                                           // [L][T][B][4H]
+  float* hs;                                              // [L][T][B][H]
+  float* cs;                                              // [L][T][B][H]
+  int T;
+  int64_t B;
+  int H;
+  int groups;
+  unsigned* sync;
+  float* xch;                                             // [group][L][2][H/8 slices][32 rows][8]
+};
+
+template <int KW>      // K per wave and operand = H / 8: 16 or 32
+__global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_dec_fwd_kernel(LstmDecArgs g) {
+  __shared__ float red[SEQ_WAVES * 32 * KS_RED_LD];
+  __shared__ __attribute__((aligned(16))) float hx[32 * 8];
+  __shared__ int s_abort;
+  constexpr int NQ = KW / 2;
+  const int H = g.H, NS = H / 8;
+  const int per8 = 8 * NS;
+  const int group = (int)(blockIdx.x % 8) + 8 * (int)(blockIdx.x / per8);
+  const int slice = (int)(blockIdx.x % per8) / 8;
+  if (group >= g.groups) return;
+  const int64_t b0 = (int64_t)group * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  unsigned* const tmo = g.sync;
+  unsigned* const cnt = g.sync + SEQ_CNT_STRIDE * (1 + group);
+  float* const xch = g.xch + (int64_t)group * DEC_L * 2 * H * 32;
+  if (threadIdx.x == 0) s_abort = 0;
+
+  const int kbase = wave * KW + NQ * hh;
+  const int64_t wrow = (int64_t)(l31 >> 3) * H + slice * 8 + (l31 & 7);
+  float wx[DEC_L][NQ], wh[DEC_L][NQ];
+#pragma unroll
+  for (int l = 0; l < DEC_L; ++l)
+#pragma unroll
+    for (int q = 0; q < NQ / 4; ++q) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(g.w_ih[l] + wrow * H + kbase + 4 * q);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(g.w_hh[l] + wrow * H + kbase + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        wx[l][4 * q + e] = a[e];
+        wh[l][4 * q + e] = b[e];
+      }
+    }
+  const int bl = threadIdx.x >> 3, jj = threadIdx.x & 7;
+  const bool cell = threadIdx.x < 256;
+  const int64_t b = b0 + bl, j = (int64_t)slice * 8 + jj;
+  const bool bok = cell && b < g.B;
+  float bias[DEC_L][4], cstate[DEC_L];
+#pragma unroll
+  for (int l = 0; l < DEC_L; ++l) {
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) bias[l][gt] = cell ? g.b_ih[l][gt * H + j] + g.b_hh[l][gt * H + j] : 0.f;
+    cstate[l] = bok ? g.c0[b * g.ld_c0 + l * H + j] : 0.f;
+  }
+  const int64_t arow = b0 + l31;
+  const bool arow_ok = arow < g.B;
+  const int64_t arc = arow_ok ? arow : g.B - 1;
+  __syncthreads();
+
+  const int ncells = g.T * DEC_L;
+#pragma unroll 1
+  for (int t = 0; t < g.T; ++t) {
+#pragma unroll
+    for (int l = 0; l < DEC_L; ++l) {
+      const int s = t * DEC_L + l;
+      if (s > 0) {
+        if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)s, &s_abort)) return;
+      }
+      // the two operands: x (the cell below, or the top layer's previous output) and this layer's previous h
+      f32x4 ax[NQ / 4], ah[NQ / 4];
+      if (l == 0 && t == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ / 4; ++q) ax[q] = *reinterpret_cast<const f32x4*>(g.init + kbase + 4 * q);
+      } else {
+        const float* src = xch + (int64_t)((l == 0 ? (DEC_L - 1) * 2 + ((t - 1) & 1) : (l - 1) * 2 + (t & 1))) * H * 32;
+#pragma unroll
+        for (int q = 0; q < NQ / 4; ++q) {
+          const int u = kbase + 4 * q;
+          ax[q] = load_x4_sc1(src + ((int64_t)(u >> 3) * 32 + l31) * 8 + (u & 7));
+        }
+      }
+      if (t == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ / 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(g.h0 + arc * g.ld_h0 + l * H + kbase + 4 * q);
+          ah[q] = arow_ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      } else {
+        const float* src = xch + (int64_t)(l * 2 + ((t - 1) & 1)) * H * 32;
+#pragma unroll
+        for (int q = 0; q < NQ / 4; ++q) {
+          const int u = kbase + 4 * q;
+          ah[q] = load_x4_sc1(src + ((int64_t)(u >> 3) * 32 + l31) * 8 + (u & 7));
+        }
+      }
+      // the write-through-coherent loads above are invisible to the compiler's wait counters
+      if constexpr (NQ / 4 == 2)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ax[0]), "+v"(ax[1]), "+v"(ah[0]), "+v"(ah[1]) : : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(ax[0]), "+v"(ax[1]), "+v"(ax[2]), "+v"(ax[3]), "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3])
+                     : : "memory");
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int q = 0; q < NQ / 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[q][e], wx[l][4 * q + e], acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < NQ / 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ah[q][e], wh[l][4 * q + e], acc, 0, 0, 0);
+      ks_spill(red, acc, wave, lane);
+      __syncthreads();
+      float ig_o = 0.f, fg_o = 0.f, gg_o = 0.f, og_o = 0.f, hn_o = 0.f;
+      if (cell) {
+        float pre[4];
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt) {
+          const int col = gt * 8 + jj;
+          float sum = 0.f;
+#pragma unroll
+          for (int w = 0; w < SEQ_WAVES; ++w) sum += red[(w * 32 + bl) * KS_RED_LD + col];
+          pre[gt] = sum + bias[l][gt];
+        }
+        ig_o = sigmoidf_(pre[0]); fg_o = sigmoidf_(pre[1]); gg_o = tanhf(pre[2]); og_o = sigmoidf_(pre[3]);
+        cstate[l] = fg_o * cstate[l] + ig_o * gg_o;
+        hn_o = og_o * tanhf(cstate[l]);
+        hx[bl * 8 + jj] = bok ? hn_o : 0.f;
+      }
+      if (s + 1 < ncells) {
+        __syncthreads();
+        if (wave == 0) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&hx[lane * 4]);
+          store_x4_sc1(xch + (int64_t)(l * 2 + (t & 1)) * H * 32 + (int64_t)slice * 256 + lane * 4, v);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add((gu32_t*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (bok) {
+        const int64_t row = ((int64_t)l * g.T + t) * g.B + b;
+        float* go = g.gates + row * 4 * H;
+        go[0 * H + j] = ig_o;
+        go[1 * H + j] = fg_o;
+        go[2 * H + j] = gg_o;
+        go[3 * H + j] = og_o;
+        g.cs[row * H + j] = cstate[l];
+        g.hs[row * H + j] = hn_o;
+      }
+    }
+  }
+}
+
+extern "C" int dvae_lstm_dec2_supported(int64_t T, int64_t B, int64_t H) {
+  if (T < 1 || B < 1 || (H != 128 && H != 256)) return 0;
+  return ceil_div64(B, 32) * (H / 8) <= 256;       // one 512-thread workgroup per compute unit, all resident
+}
+
+extern "C" int64_t dvae_lstm_dec2_ws_floats(int64_t B, int64_t H) {
+  const int64_t groups = ceil_div64(B, 32);
+  // counters, then the larger of the forward (hidden states) and backward (partial products) exchange areas
+  return SEQ_CNT_STRIDE * (1 + groups) + groups * DEC_L * 2 * 2 * (H / 8) * 32 * H;
+}
+
+extern "C" int dvae_lstm_dec2_fwd_f32(const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
+                                      const float* const* b_hh, const float* h0, int64_t ld_h0, const float* c0,
+                                      int64_t ld_c0, const float* init, float* gates, float* hs, float* cs, int64_t T,
+                                      int64_t B, int64_t H, float* ws, dvae_stream_t stream) {
+  DVAE_REQUIRE(dvae_lstm_dec2_supported(T, B, H),
+               "lstm_dec2_fwd: unsupported shape (T=%ld B=%ld H=%ld): H must be 128 or 256 and ceil(B/32)*(H/8) at most 256",
+               (long)T, (long)B, (long)H);
+  DVAE_REQUIRE(w_ih && w_hh && b_ih && b_hh && h0 && c0 && init && gates && hs && cs, "lstm_dec2_fwd: null argument");
+  DVAE_REQUIRE(ws != nullptr && (((uintptr_t)ws) & 255) == 0, "lstm_dec2_fwd: workspace must be 256-byte aligned");
+  DVAE_REQUIRE(aligned16(h0) && ld_h0 % 4 == 0 && aligned16(init), "lstm_dec2_fwd: h0 and init must be 16-byte aligned");
+  LstmDecArgs g;
+  for (int l = 0; l < DEC_L; ++l) {
+    g.w_ih[l] = w_ih[l]; g.w_hh[l] = w_hh[l]; g.b_ih[l] = b_ih[l]; g.b_hh[l] = b_hh[l];
+    DVAE_REQUIRE(g.w_ih[l] && g.w_hh[l] && g.b_ih[l] && g.b_hh[l] && aligned16(g.w_ih[l]) && aligned16(g.w_hh[l]),
+                 "lstm_dec2_fwd: weights of layer %d missing or not 16-byte aligned", l);
+  }
+  g.h0 = h0; g.ld_h0 = ld_h0; g.c0 = c0; g.ld_c0 = ld_c0; g.init = init;
+  g.gates = gates; g.hs = hs; g.cs = cs; g.T = (int)T; g.B = B; g.H = (int)H;
+  g.groups = (int)ceil_div64(B, 32);
+  g.sync = (unsigned*)ws;
+  g.xch = ws + SEQ_CNT_STRIDE * (1 + g.groups);
+  if (hipMemsetAsync(ws, 0, sizeof(unsigned) * SEQ_CNT_STRIDE * (1 + g.groups), ST(stream)) != hipSuccess) {
+    dvae_set_error("lstm_dec2_fwd: clearing the counters failed: %s", hipGetErrorString(hipGetLastError()));
+    return -EIO;
+  }
+  const int NS = (int)(H / 8);
+  const unsigned nblocks = (unsigned)(8 * NS * ((g.groups + 7) / 8));
+  DVAE_WORK(2.0 * (double)DEC_L * T * B * 4 * H * 2 * H, DVAE_UNIT_FLOP);
+  if (H == 128) DVAE_LAUNCH((lstm_dec_fwd_kernel<16>), dim3(nblocks), dim3(64 * SEQ_WAVES), 0, ST(stream), g);
+  else DVAE_LAUNCH((lstm_dec_fwd_kernel<32>), dim3(nblocks), dim3(64 * SEQ_WAVES), 0, ST(stream), g);
+  DVAE_LAUNCH_CHECK("lstm_dec2_fwd");
+  return 0;
+}

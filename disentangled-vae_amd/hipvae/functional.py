@@ -567,7 +567,11 @@ class LSTMDecoder(torch.autograd.Function):
         # x W_ih^T + h W_hh^T = h (W_ih + W_hh)^T and the step is H deep instead of 2H
         w_comb = (w[0] + w[1]) if (L == 1 and T > 1) else None
         seq = w_comb is not None and USE_SEQ_KERNELS and ops.lstm_seq_supported(1, T - 1, B, H)
-        for t in range(1 if seq else T):
+        dec2 = L == 2 and USE_SEQ_KERNELS and ops.lstm_dec2_supported(T, B, H)
+        if dec2:
+            # both layers' cells of all T steps as one chain in one launch, the four weight slices in registers
+            ops.lstm_dec2_fwd(w, h0, c0, init_c.view(-1), gates, hs, cs)
+        for t in range(0 if dec2 else 1 if seq else T):
             for l in range(L):
                 h_prev = h0[:, l * H:(l + 1) * H] if t == 0 else hs[l, t - 1]
                 c_prev = c0[:, l * H:(l + 1) * H] if t == 0 else cs[l, t - 1]

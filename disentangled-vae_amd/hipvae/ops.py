@@ -756,6 +756,25 @@ def lstm_seq_bwd(chains, T: int, B: int, H: int, accumulate_dh_init: bool = Fals
     return ws
 
 
+def lstm_dec2_supported(T: int, B: int, H: int) -> bool:
+    return bool(lib.dvae_lstm_dec2_supported(T, B, H))
+
+
+def lstm_dec2_fwd(weights, h0: Tensor, c0: Tensor, init: Tensor, gates: Tensor, hs: Tensor, cs: Tensor):
+    """The two-layer autoregressive decoder loop in one launch.  weights: w_ih, w_hh, b_ih, b_hh of layer 0, then of
+    layer 1; h0 / c0 [B, 2H]; init [H]; outputs gates [2,T,B,4H], hs / cs [2,T,B,H]."""
+    _chk(*weights, h0, c0, init, gates, hs, cs)
+    L, T, B, H = hs.shape
+    assert L == 2 and len(weights) == 8 and h0.shape == (B, 2 * H) and c0.shape == (B, 2 * H) and init.numel() == H
+    assert gates.shape == (2, T, B, 4 * H) and cs.shape == hs.shape
+    assert all(weights[4 * l + k].shape == (4 * H, H) for l in range(2) for k in range(2))
+    ws = workspace(lib.dvae_lstm_dec2_ws_floats(B, H), h0.device, 'lstm_seq')
+    arr = lambda k: _ptr_array([weights[k], weights[4 + k]])
+    check(lib.dvae_lstm_dec2_fwd_f32(arr(0), arr(1), arr(2), arr(3), _p(h0), h0.stride(0), _p(c0), c0.stride(0),
+                                     _p(init), _p(gates), _p(hs), _p(cs), T, B, H, _p(ws), _stream()), 'lstm_dec2_fwd')
+    return ws
+
+
 # ---------------------------------------------------------------------------- optimiser
 class TensorTable:
     """Host-side pointer/size arrays for the multi-tensor kernels, rebuilt only when pointers move."""

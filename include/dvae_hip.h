@@ -402,6 +402,20 @@ int dvae_lstm_seq_bwd_f32(int64_t nchains, const float* const* w_rec, const floa
                           int accumulate_dh_init, const int* reverse, int64_t T, int64_t B, int64_t H, float* ws,
                           dvae_stream_t stream);
 
+/* ---- the stacked (two-layer) autoregressive decoder loop of LSTMDecoder (models/decoders.py:110-137) in ONE launch.
+ *      Cell (t, l): pre = x W_ih_l^T + h_{l,t-1} W_hh_l^T + b_ih_l + b_hh_l with x = h_{1,t-1} for layer 0 (init, the
+ *      same [H] vector for every row, at t = 0) and x = h_{0,t} for layer 1; initial states h0 / c0 [B][2H] (layer l
+ *      in columns l*H..).  Host arrays of two device pointers (layer 0, layer 1), weights [4H][H], biases [4H].
+ *      Outputs gates [2][T][B][4H] (activated), hs / cs [2][T][B][H].  dvae_lstm_dec2_supported(): H in {128, 256}
+ *      and ceil(B/32)*(H/8) <= 256 (every workgroup resident, one per compute unit); otherwise -EINVAL (use the
+ *      per-step calls).  ws: dvae_lstm_dec2_ws_floats(B, H) floats, 256-byte aligned, ws[0] as in dvae_lstm_seq_fwd_f32. */
+int dvae_lstm_dec2_supported(int64_t T, int64_t B, int64_t H);
+int64_t dvae_lstm_dec2_ws_floats(int64_t B, int64_t H);
+int dvae_lstm_dec2_fwd_f32(const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
+                           const float* const* b_hh, const float* h0, int64_t ld_h0, const float* c0, int64_t ld_c0,
+                           const float* init, float* gates, float* hs, float* cs, int64_t T, int64_t B, int64_t H,
+                           float* ws, dvae_stream_t stream);
+
 /* ---- optimiser (torch.optim.Adam with L2 weight decay and nn.utils.clip_grad_norm_ as called at
  *      training/trainer.py:56-61,198-204).  Host arrays of n device pointers / sizes.
  *      dvae_grad_norm: total 2-norm of all gradients -> norm_out[0], and

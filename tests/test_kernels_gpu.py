@@ -639,6 +639,40 @@ def test_lstm_seq_bwd_hands_on_the_initial_state_gradients(ops, T, B, H):
     assert rel_err(dh_init, r['h_init'].grad) < 1e-5
 
 
+@pytest.mark.parametrize('T,B,H', [(20, 32, 256), (5, 70, 128), (3, 256, 256), (1, 7, 128)])
+def test_lstm_dec2_fwd_stacked_decoder_in_one_launch(ops, T, B, H):
+    """dvae_lstm_dec2_fwd_f32 against the fp64 loop of two stacked cells fed with the top layer's previous output"""
+    assert ops.lstm_dec2_supported(T, B, H)
+    ws_ = [rnd(4 * H, H, seed=400 + k, scale=0.08) for k in range(4)]          # w_ih0, w_hh0, w_ih1, w_hh1
+    bs_ = [rnd(4 * H, seed=410 + k, scale=0.1) for k in range(4)]              # b_ih0, b_hh0, b_ih1, b_hh1
+    h0, c0, init = rnd(B, 2 * H, seed=420), rnd(B, 2 * H, seed=421), rnd(H, seed=422)
+    h = [h0[:, :H], h0[:, H:]]
+    c = [c0[:, :H], c0[:, H:]]
+    x = init.expand(B, H)
+    ref_h = torch.zeros(2, T, B, H, dtype=torch.float64)
+    ref_c = torch.zeros(2, T, B, H, dtype=torch.float64)
+    for t in range(T):
+        for l in range(2):
+            xin = x if l == 0 else h[0]
+            proj = xin @ ws_[2 * l].t() + bs_[2 * l] + bs_[2 * l + 1]
+            h[l], c[l] = O.lstm_cell(proj, h[l], c[l], ws_[2 * l + 1])
+            ref_h[l, t], ref_c[l, t] = h[l], c[l]
+        x = h[1]
+    weights = [dev(ws_[0]), dev(ws_[1]), dev(bs_[0]), dev(bs_[1]), dev(ws_[2]), dev(ws_[3]), dev(bs_[2]), dev(bs_[3])]
+    gates = torch.empty(2, T, B, 4 * H, device='cuda')
+    hs, cs = torch.empty(2, T, B, H, device='cuda'), torch.empty(2, T, B, H, device='cuda')
+    ws = ops.lstm_dec2_fwd(weights, dev(h0), dev(c0), dev(init), gates, hs, cs)
+    torch.cuda.synchronize()
+    assert int(ws[:1].view(torch.int32).item()) == 0, 'a wait inside the launch ran into its time bound'
+    assert rel_err(hs, ref_h) < 1e-5 and rel_err(cs, ref_c) < 1e-5
+    # the activated output gate reproduces h from c
+    o = gates[:, :, :, 3 * H:]
+    assert rel_err(o * torch.tanh(cs), ref_h) < 1e-5
+    first = hs.clone()
+    ops.lstm_dec2_fwd(weights, dev(h0), dev(c0), dev(init), gates, hs, cs)
+    assert torch.equal(first, hs)
+
+
 def test_lstm_seq_rejects_what_cannot_be_resident(ops):
     assert not ops.lstm_seq_supported(2, 19, 512, 256)           # 1024 workgroups
     assert not ops.lstm_seq_supported(1, 19, 32, 32)             # hidden size without a kernel
