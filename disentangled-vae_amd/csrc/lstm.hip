@@ -1189,3 +1189,220 @@ extern "C" int dvae_lstm_dec2_fwd_f32(const float* const* w_ih, const float* con
   DVAE_LAUNCH_CHECK("lstm_dec2_fwd");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Stacked decoder, backward through the chain of cells in ONE launch: (T-1,1) (T-1,0) (T-2,1) ... (0,0).
+//
+// A hidden state h_{l,t} receives at most two products: A, the input path of the cell it feeds as x (layer 1 at
+// the same step for l = 0; layer 0 at the next step for the top layer), and B, its own layer's recurrent path
+// from step t+1.  Each cell therefore publishes two 32 x H partial products (dG W_ih_l and dG W_hh_l, as in
+// lstm_seq_bwd_kernel) into the buffers of their destination cells -- kind (A/B) x destination layer x parity of
+// the destination step -- and gathers its own two before its pointwise step.  What leaves the chain at its end
+// (destination step -1) is the gradient of the initial hidden states and of the first input.
+// ------------------------------------------------------------------------------------------------
+struct LstmDecBwdArgs {
+  const float* w_ih[DEC_L]; const float* w_hh[DEC_L];     // [4H][H]
+  const float* gates;                                     // [L][T][B][4H]
+  const float* cs;                                        // [L][T][B][H]
+  const float* c0; int64_t ld_c0;                         // [B][L*H]
+  const float* dstates; int64_t ld_ds; int64_t step_ds;   // gradient reaching h_{L-1,t}[b][j]: + t*step_ds + b*ld_ds + j
+  float* dgates;                                          // [L][T][B][4H]
+  float* dh0; int64_t ld_dh0;                             // [B][L*H]
+  float* dc0; int64_t ld_dc0;                             // [B][L*H]
+  float* dx0;                                             // [B][H]: gradient wrt layer 0's first input, per row
+  int T;
+  int64_t B;
+  int groups;
+  unsigned* sync;
+  float* xch;                                             // [group][kind][layer][parity][writer][dest][32][8]
+};
+
+template <int HH>      // hidden size: 128 or 256 (one 32-column tile per wave at most)
+__global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_dec_bwd_kernel(LstmDecBwdArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[32 * SEQ_A_LD];
+  __shared__ __attribute__((aligned(16))) float Ts[SEQ_WAVES * 32 * SEQ_A_LD];
+  __shared__ __attribute__((aligned(16))) float red[SEQ_WAVES * 32 * 8];
+  __shared__ int s_abort;
+  constexpr int H = HH, NS = HH / 8, NTILE = HH / 32, NW = NS / SEQ_WAVES;
+  static_assert(NTILE <= SEQ_WAVES, "one product tile per wave");
+  const int per8 = 8 * NS;
+  const int group = (int)(blockIdx.x % 8) + 8 * (int)(blockIdx.x / per8);
+  const int slice = (int)(blockIdx.x % per8) / 8;
+  if (group >= g.groups) return;
+  const int64_t b0 = (int64_t)group * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  unsigned* const tmo = g.sync;
+  unsigned* const cnt = g.sync + SEQ_CNT_STRIDE * (1 + group);
+  constexpr unsigned XBUF = (unsigned)NS * 32u * H;         // floats per buffer
+  constexpr unsigned NBUF = 2 * DEC_L * 2;
+  const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(g.xch + (int64_t)group * NBUF * XBUF, 0, NBUF * XBUF * 4, 0x00020000);
+  auto buf_of = [](int kind, int layer, int parity) { return (unsigned)((kind * DEC_L + layer) * 2 + (parity & 1)); };
+  if (threadIdx.x == 0) s_abort = 0;
+
+  // weight rows of this workgroup's 32 gate columns, both matrices of both layers (see lstm_seq_bwd_kernel)
+  const bool has_tile = wave < NTILE;
+  float wx[DEC_L][16], wh[DEC_L][16];
+#pragma unroll
+  for (int l = 0; l < DEC_L; ++l)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = 16 * hh + i;
+      const int64_t off = ((int64_t)(k >> 3) * H + slice * 8 + (k & 7)) * H + wave * 32 + l31;
+      wx[l][i] = has_tile ? g.w_ih[l][off] : 0.f;
+      wh[l][i] = has_tile ? g.w_hh[l][off] : 0.f;
+    }
+  const int bl = threadIdx.x >> 3, jj = threadIdx.x & 7;
+  const bool cell = threadIdx.x < 256;
+  const int64_t b = b0 + bl, j = (int64_t)slice * 8 + jj;
+  const bool bok = cell && b < g.B;
+  const int xrow = lane >> 1, xhalf = lane & 1;
+  float dcarry[DEC_L] = {0.f, 0.f};
+  __syncthreads();
+
+  // sum over all writers of this slice's 32 x 8 block of up to two buffers (fixed order), left in `red`
+  auto gather = [&](bool use_a, unsigned buf_a, bool use_b, unsigned buf_b) {
+    u32x4 va[NW], vb[NW];
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const unsigned w = (unsigned)(wave * NW + q);
+      const unsigned off = (w * 32u * H + (unsigned)slice * 256u + (unsigned)lane * 4u) * 4u;
+      va[q] = use_a ? __builtin_amdgcn_raw_buffer_load_b128(xrsrc, buf_a * XBUF * 4u + off, 0, SEQ_AUX_SC1) : (u32x4){0u, 0u, 0u, 0u};
+      vb[q] = use_b ? __builtin_amdgcn_raw_buffer_load_b128(xrsrc, buf_b * XBUF * 4u + off, 0, SEQ_AUX_SC1) : (u32x4){0u, 0u, 0u, 0u};
+    }
+    f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NW; ++q) sum += __builtin_bit_cast(f32x4, va[q]);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) sum += __builtin_bit_cast(f32x4, vb[q]);
+    *reinterpret_cast<f32x4*>(&red[(wave * 32 + xrow) * 8 + xhalf * 4]) = sum;
+    __syncthreads();
+  };
+  auto gathered = [&]() {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < SEQ_WAVES; ++w) sum += red[(w * 32 + bl) * 8 + jj];
+    return sum;
+  };
+  // this wave's 32 x 32 tile of dG * (rows of W) into destination order and out (see lstm_seq_bwd_kernel)
+  auto product = [&](const f32x4 (&av)[4], const float (&w)[16], unsigned buf) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][e], w[4 * q + e], acc, 0, 0, 0);
+    float* const tsw = Ts + wave * 32 * SEQ_A_LD;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tsw[((r & 3) + 8 * (r >> 2) + 4 * hh) * SEQ_A_LD + l31] = acc[r];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&tsw[xrow * SEQ_A_LD + q * 8 + xhalf * 4]);
+      const unsigned off = (buf * XBUF + (unsigned)slice * 32u * H + (unsigned)(wave * 4 + q) * 256u + (unsigned)lane * 4u) * 4u;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xrsrc, off, 0, SEQ_AUX_SC1);
+    }
+  };
+
+  const int T = g.T;
+#pragma unroll 1
+  for (int t = T - 1; t >= 0; --t) {
+#pragma unroll
+    for (int l = DEC_L - 1; l >= 0; --l) {
+      const int sigma = (T - 1 - t) * DEC_L + (DEC_L - 1 - l);
+      float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cv = 0.f, cpv = 0.f, dhv = 0.f;
+      const int64_t row = ((int64_t)l * T + t) * g.B + b;
+      if (bok) {
+        const float* gt = g.gates + row * 4 * H + j;
+        ig = gt[0]; fg = gt[H]; gg = gt[2 * H]; og = gt[3 * H];
+        cv = g.cs[row * H + j];
+        cpv = t > 0 ? g.cs[(row - g.B) * H + j] : g.c0[b * g.ld_c0 + l * H + j];
+        if (l == DEC_L - 1) dhv = g.dstates[(int64_t)t * g.step_ds + b * g.ld_ds + j];
+      }
+      if (sigma > 0) {
+        if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)sigma, &s_abort)) return;
+        const bool use_a = !(l == DEC_L - 1 && t == T - 1), use_b = t < T - 1;
+        gather(use_a, buf_of(0, l, t), use_b, buf_of(1, l, t));
+        if (cell) dhv += gathered();
+      }
+      float dg0 = 0.f, dg1 = 0.f, dg2 = 0.f, dg3 = 0.f;
+      if (cell) {
+        const float tc = tanhf(cv);
+        const float dct = dcarry[l] + dhv * og * (1.f - tc * tc);
+        dg0 = dct * gg * ig * (1.f - ig);
+        dg1 = dct * cpv * fg * (1.f - fg);
+        dg2 = dct * ig * (1.f - gg * gg);
+        dg3 = dhv * tc * og * (1.f - og);
+        dcarry[l] = dct * fg;
+        if (!bok) dg0 = dg1 = dg2 = dg3 = 0.f;
+        As[bl * SEQ_A_LD + 0 * 8 + jj] = dg0;
+        As[bl * SEQ_A_LD + 1 * 8 + jj] = dg1;
+        As[bl * SEQ_A_LD + 2 * 8 + jj] = dg2;
+        As[bl * SEQ_A_LD + 3 * 8 + jj] = dg3;
+      }
+      __syncthreads();
+      if (has_tile) {
+        f32x4 av[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const f32x4*>(&As[l31 * SEQ_A_LD + 16 * hh + 4 * q]);
+        // input path: to the cell that fed this one its x; recurrent path: to this layer's previous step
+        product(av, wx[l], l > 0 ? buf_of(0, l - 1, t) : buf_of(0, DEC_L - 1, t - 1));
+        product(av, wh[l], buf_of(1, l, t - 1));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_fetch_add((gu32_t*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (bok) {
+        float* dg = g.dgates + row * 4 * H + j;
+        dg[0] = dg0; dg[H] = dg1; dg[2 * H] = dg2; dg[3 * H] = dg3;
+      }
+    }
+  }
+  // what left the chain at its end: destination step -1 (odd parity)
+  if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)(T * DEC_L), &s_abort)) return;
+#pragma unroll
+  for (int l = 0; l < DEC_L; ++l) {
+    gather(false, 0u, true, buf_of(1, l, -1));
+    if (bok) {
+      g.dh0[b * g.ld_dh0 + l * H + j] = gathered();
+      g.dc0[b * g.ld_dc0 + l * H + j] = dcarry[l];
+    }
+    __syncthreads();
+  }
+  gather(true, buf_of(0, DEC_L - 1, -1), false, 0u);
+  if (bok) g.dx0[b * H + j] = gathered();
+}
+
+extern "C" int dvae_lstm_dec2_bwd_f32(const float* const* w_ih, const float* const* w_hh, const float* gates,
+                                      const float* cs, const float* c0, int64_t ld_c0, const float* dstates,
+                                      int64_t ld_ds, int64_t step_ds, float* dgates, float* dh0, int64_t ld_dh0,
+                                      float* dc0, int64_t ld_dc0, float* dx0, int64_t T, int64_t B, int64_t H,
+                                      float* ws, dvae_stream_t stream) {
+  DVAE_REQUIRE(dvae_lstm_dec2_supported(T, B, H),
+               "lstm_dec2_bwd: unsupported shape (T=%ld B=%ld H=%ld): H must be 128 or 256 and ceil(B/32)*(H/8) at most 256",
+               (long)T, (long)B, (long)H);
+  DVAE_REQUIRE(w_ih && w_hh && gates && cs && c0 && dstates && dgates && dh0 && dc0 && dx0, "lstm_dec2_bwd: null argument");
+  DVAE_REQUIRE(ws != nullptr && (((uintptr_t)ws) & 255) == 0, "lstm_dec2_bwd: workspace must be 256-byte aligned");
+  LstmDecBwdArgs g;
+  for (int l = 0; l < DEC_L; ++l) {
+    g.w_ih[l] = w_ih[l]; g.w_hh[l] = w_hh[l];
+    DVAE_REQUIRE(g.w_ih[l] && g.w_hh[l], "lstm_dec2_bwd: weights of layer %d missing", l);
+  }
+  g.gates = gates; g.cs = cs; g.c0 = c0; g.ld_c0 = ld_c0;
+  g.dstates = dstates; g.ld_ds = ld_ds; g.step_ds = step_ds;
+  g.dgates = dgates; g.dh0 = dh0; g.ld_dh0 = ld_dh0; g.dc0 = dc0; g.ld_dc0 = ld_dc0; g.dx0 = dx0;
+  g.T = (int)T; g.B = B; g.groups = (int)ceil_div64(B, 32);
+  g.sync = (unsigned*)ws;
+  g.xch = ws + SEQ_CNT_STRIDE * (1 + g.groups);
+  if (hipMemsetAsync(ws, 0, sizeof(unsigned) * SEQ_CNT_STRIDE * (1 + g.groups), ST(stream)) != hipSuccess) {
+    dvae_set_error("lstm_dec2_bwd: clearing the counters failed: %s", hipGetErrorString(hipGetLastError()));
+    return -EIO;
+  }
+  const int NS = (int)(H / 8);
+  const unsigned nblocks = (unsigned)(8 * NS * ((g.groups + 7) / 8));
+  DVAE_WORK(2.0 * (double)DEC_L * T * B * 4 * H * 2 * H, DVAE_UNIT_FLOP);
+  if (H == 128) DVAE_LAUNCH((lstm_dec_bwd_kernel<128>), dim3(nblocks), dim3(64 * SEQ_WAVES), 0, ST(stream), g);
+  else DVAE_LAUNCH((lstm_dec_bwd_kernel<256>), dim3(nblocks), dim3(64 * SEQ_WAVES), 0, ST(stream), g);
+  DVAE_LAUNCH_CHECK("lstm_dec2_bwd");
+  return 0;
+}

@@ -99,6 +99,7 @@ SIGNATURES = {
     'dvae_lstm_dec2_supported': (I, [L, L, L]),
     'dvae_lstm_dec2_ws_floats': (L, [L, L]),
     'dvae_lstm_dec2_fwd_f32': (I, [POINTER(c_void_p)] * 4 + [P, L, P, L, P, P, P, P, L, L, L, P, P]),
+    'dvae_lstm_dec2_bwd_f32': (I, [POINTER(c_void_p)] * 2 + [P, P, P, L, P, L, L, P, P, L, P, L, P, L, L, L, P, P]),
     'dvae_grad_norm_ws_floats': (L, [L, POINTER(c_int64)]),
     'dvae_grad_norm_f32': (I, [L, POINTER(c_void_p), POINTER(c_int64), F, P, P, P]),
     'dvae_scale_tensors_f32': (I, [L, POINTER(c_void_p), POINTER(c_int64), P, P]),

@@ -601,16 +601,21 @@ class LSTMDecoder(torch.autograd.Function):
         saved = ctx.saved_tensors
         h0, c0, init_c, hs, cs, gates = saved[:6]
         weights = [t.contiguous() for t in saved[6:]]
+        dg = _empty(L, T, B, 4 * H, like=h0)
+        dh0 = _empty(B, L * H, like=h0)
+        dc0 = _empty(B, L * H, like=h0)
+        dx0 = _empty(B, H, like=h0)
+        dec2 = L == 2 and USE_SEQ_KERNELS and ops.lstm_dec2_supported(T, B, H)
+        if dec2:
+            # the whole chain of cells backwards in one launch
+            ops.lstm_dec2_bwd(weights, gates, cs, c0, dstates.contiguous(), dg, dh0, dc0, dx0)
+            return LSTMDecoder._weight_grads(B, T, L, H, h0, init_c, hs, dg, dh0, dc0, dx0)
         if L == 1:
             dhs = ops.permute3(dstates.contiguous(), (B, T, H), (1, 0, 2)).view(1, T, B, H)
         else:
             dhs = _zeros(L, T, B, H, like=h0)
             dhs[L - 1] = ops.permute3(dstates.contiguous(), (B, T, H), (1, 0, 2))
-        dg = _empty(L, T, B, 4 * H, like=h0)
-        dh0 = _empty(B, L * H, like=h0)
-        dc0 = _empty(B, L * H, like=h0)
         dcbuf = [[_empty(B, H, like=h0), _empty(B, H, like=h0)] for _ in range(L)]
-        dx0 = _empty(B, H, like=h0)
         # dh = dG * W needs W's columns as k-contiguous rows: transposed copies, once per backward;
         # for a single layer both paths of a step t > 0 end in h_{t-1}, so they share W_ih + W_hh
         w_ih_t = [weights[4 * l].t().contiguous() for l in range(L)]
@@ -678,6 +683,11 @@ class LSTMDecoder(torch.autograd.Function):
                 else:
                     ops.skinny_gemm_nt(dg[0, 0], w_hh, rec_target, False)
                     ops.skinny_gemm_nt(dg[0, 0], w_ih, dx0, False)
+        return LSTMDecoder._weight_grads(B, T, L, H, h0, init_c, hs, dg, dh0, dc0, dx0)
+
+    @staticmethod
+    def _weight_grads(B, T, L, H, h0, init_c, hs, dg, dh0, dc0, dx0):
+        """the hoisted part of the backward: every weight gradient is one GEMM over all steps' gate gradients"""
         dinit = ops.bias_act_bwd(dx0, None, ops.ACT_NONE, True).view(1, H)
         grads = [None] * (4 * L)
         for l in range(L):

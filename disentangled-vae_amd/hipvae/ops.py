@@ -775,6 +775,22 @@ def lstm_dec2_fwd(weights, h0: Tensor, c0: Tensor, init: Tensor, gates: Tensor, 
     return ws
 
 
+def lstm_dec2_bwd(weights, gates: Tensor, cs: Tensor, c0: Tensor, dstates: Tensor, dgates: Tensor, dh0: Tensor,
+                  dc0: Tensor, dx0: Tensor):
+    """Backward of lstm_dec2_fwd in one launch.  dstates [B,T,H] (the gradient of the top layer's outputs, batch-major
+    as the decoder returns them); outputs dgates [2,T,B,4H], dh0 / dc0 [B,2H], dx0 [B,H]."""
+    _chk(*[w for w in weights if w is not None], gates, cs, c0, dstates, dgates, dh0, dc0, dx0)
+    L, T, B, H = cs.shape
+    assert L == 2 and dstates.shape == (B, T, H) and dgates.shape == gates.shape == (2, T, B, 4 * H)
+    assert c0.shape == dh0.shape == dc0.shape == (B, 2 * H) and dx0.shape == (B, H)
+    ws = workspace(lib.dvae_lstm_dec2_ws_floats(B, H), c0.device, 'lstm_seq')
+    arr = lambda k: _ptr_array([weights[k], weights[4 + k]])
+    check(lib.dvae_lstm_dec2_bwd_f32(arr(0), arr(1), _p(gates), _p(cs), _p(c0), c0.stride(0), _p(dstates), T * H, H,
+                                     _p(dgates), _p(dh0), dh0.stride(0), _p(dc0), dc0.stride(0), _p(dx0), T, B, H,
+                                     _p(ws), _stream()), 'lstm_dec2_bwd')
+    return ws
+
+
 # ---------------------------------------------------------------------------- optimiser
 class TensorTable:
     """Host-side pointer/size arrays for the multi-tensor kernels, rebuilt only when pointers move."""

@@ -415,6 +415,14 @@ int dvae_lstm_dec2_fwd_f32(const float* const* w_ih, const float* const* w_hh, c
                            const float* const* b_hh, const float* h0, int64_t ld_h0, const float* c0, int64_t ld_c0,
                            const float* init, float* gates, float* hs, float* cs, int64_t T, int64_t B, int64_t H,
                            float* ws, dvae_stream_t stream);
+/* its backward through the chain of cells in ONE launch.  gates / cs: the forward call's outputs; dstates: the
+ * gradient reaching the top layer's h of step t at dstates + t*step_ds + b*ld_ds; outputs dgates [2][T][B][4H]
+ * (gradient wrt the gate pre-activations: the operand of every weight-gradient GEMM), dh0 / dc0 [B][2H] (initial
+ * states) and dx0 [B][H] (layer 0's first input, per row).  Partial products are added in a fixed order. */
+int dvae_lstm_dec2_bwd_f32(const float* const* w_ih, const float* const* w_hh, const float* gates, const float* cs,
+                           const float* c0, int64_t ld_c0, const float* dstates, int64_t ld_ds, int64_t step_ds,
+                           float* dgates, float* dh0, int64_t ld_dh0, float* dc0, int64_t ld_dc0, float* dx0,
+                           int64_t T, int64_t B, int64_t H, float* ws, dvae_stream_t stream);
 
 /* ---- optimiser (torch.optim.Adam with L2 weight decay and nn.utils.clip_grad_norm_ as called at
  *      training/trainer.py:56-61,198-204).  Host arrays of n device pointers / sizes.

@@ -673,6 +673,51 @@ def test_lstm_dec2_fwd_stacked_decoder_in_one_launch(ops, T, B, H):
     assert torch.equal(first, hs)
 
 
+@pytest.mark.parametrize('T,B,H', [(20, 32, 256), (5, 70, 128), (3, 256, 256), (1, 7, 128)])
+def test_lstm_dec2_bwd_stacked_decoder_in_one_launch(ops, T, B, H):
+    """dvae_lstm_dec2_bwd_f32 against fp64 autograd of the stacked decoder loop: gate gradients of every cell,
+    gradients of both initial states and of the first input."""
+    ws_ = [rnd(4 * H, H, seed=430 + k, scale=0.08) for k in range(4)]          # w_ih0, w_hh0, w_ih1, w_hh1
+    h0 = rnd(B, 2 * H, seed=440).requires_grad_(True)
+    c0 = rnd(B, 2 * H, seed=441).requires_grad_(True)
+    x0 = rnd(B, H, seed=442).requires_grad_(True)          # per-row first input (the model broadcasts one vector)
+    ext = rnd(B, T, H, seed=443)
+    pres = [[None] * T for _ in range(2)]
+    h = [h0[:, :H], h0[:, H:]]
+    c = [c0[:, :H], c0[:, H:]]
+    x = x0
+    gates = torch.zeros(2, T, B, 4 * H, dtype=torch.float64)
+    cs = torch.zeros(2, T, B, H, dtype=torch.float64)
+    loss = 0.0
+    for t in range(T):
+        for l in range(2):
+            xin = x if l == 0 else h[0]
+            pre = xin @ ws_[2 * l].t() + h[l] @ ws_[2 * l + 1].t()
+            pre.retain_grad()
+            pres[l][t] = pre
+            i, f, g, o = pre.chunk(4, 1)
+            i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+            c[l] = f * c[l] + i * g
+            h[l] = o * torch.tanh(c[l])
+            gates[l, t], cs[l, t] = torch.cat([i, f, g, o], 1).detach(), c[l].detach()
+        x = h[1]
+        loss = loss + (h[1] * ext[:, t]).sum()
+    loss.backward()
+    ref_dg = torch.stack([torch.stack([pres[l][t].grad for t in range(T)]) for l in range(2)])
+    weights = [dev(ws_[0]), dev(ws_[1]), None, None, dev(ws_[2]), dev(ws_[3]), None, None]
+    dg = torch.empty(2, T, B, 4 * H, device='cuda')
+    dh0, dc0 = torch.empty(B, 2 * H, device='cuda'), torch.empty(B, 2 * H, device='cuda')
+    dx0 = torch.empty(B, H, device='cuda')
+    ws = ops.lstm_dec2_bwd(weights, dev(gates), dev(cs), dev(c0.detach()), dev(ext), dg, dh0, dc0, dx0)
+    torch.cuda.synchronize()
+    assert int(ws[:1].view(torch.int32).item()) == 0, 'a wait inside the launch ran into its time bound'
+    assert rel_err(dg, ref_dg) < 1e-5
+    assert rel_err(dh0, h0.grad) < 1e-5 and rel_err(dc0, c0.grad) < 1e-5 and rel_err(dx0, x0.grad) < 1e-5
+    first = dg.clone()
+    ops.lstm_dec2_bwd(weights, dev(gates), dev(cs), dev(c0.detach()), dev(ext), dg, dh0, dc0, dx0)
+    assert torch.equal(first, dg)
+
+
 def test_lstm_seq_rejects_what_cannot_be_resident(ops):
     assert not ops.lstm_seq_supported(2, 19, 512, 256)           # 1024 workgroups
     assert not ops.lstm_seq_supported(1, 19, 32, 32)             # hidden size without a kernel
