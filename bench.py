@@ -351,6 +351,7 @@ def main():
                 upload(i + 1)       # waits for step i-1 (the other buffer's last reader), then runs beside step i
                 return inner(i)
     elapsed, last = measure(step, args.steps, args.warmup)
+    ops.check_lstm_seq_timeouts()          # a one-launch LSTM kernel that was not fully resident would void the run
     value = world * B * args.steps / elapsed
     dtype_label, prec_label = PRECISION_LABEL[args.precision]
     peak_tflops = PEAK_BF16_MFMA_TFLOPS if args.precision == 'bf16' else PEAK_FP32_MFMA_TFLOPS

@@ -422,7 +422,7 @@ extern "C" int dvae_skinny_gemm_nt_f32(const float* a, int64_t ld_a, const float
 #define SEQ_WAVES 8
 #define SEQ_MAX_CHAINS 2
 #define SEQ_CNT_STRIDE 64                    // unsigned words between the counters of two groups (256 B)
-#define LSTM_SEQ_TIMEOUT_TICKS 4000000LL     // of the 100 MHz wall clock: 40 ms
+#define LSTM_SEQ_TIMEOUT_TICKS 20000000LL    // of the 100 MHz wall clock: 200 ms
 
 struct LstmSeqChain {
   const float* xproj;        // [T][B][4H] input projections without bias, or nullptr
@@ -460,6 +460,21 @@ __device__ __forceinline__ f32x4 load_x4_sc1(const float* p) {
 __device__ __forceinline__ void store_x4_sc1(float* p, f32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
+
+// Arrival counters and the timeout word start every launch at zero.  A small kernel in front of the launch, not
+// a memset: replayed from a captured graph, a memset node was seen to land while the kernel behind it was
+// already running (workgroups then read a non-zero timeout word and gave up).
+__global__ void seq_zero_kernel(unsigned* p, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+static int seq_clear(float* ws, int groups, hipStream_t stream) {
+  hipLaunchKernelGGL(seq_zero_kernel, dim3(1), dim3(256), 0, stream, (unsigned*)ws, SEQ_CNT_STRIDE * (1 + groups));
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Bounded waits that ran out, counted per GPU and never cleared by a launch (the per-launch word in the
+// workspace is): read back by dvae_lstm_seq_timeouts() at a point where the caller synchronises anyway.
+static __device__ unsigned g_seq_timeouts;
 
 template <int KW>      // K per wave = H / 8: 16, 32 or 64
 __global__ void __launch_bounds__(64 * SEQ_WAVES, SEQ_WAVES / 2) lstm_seq_fwd_kernel(LstmSeqArgs g) {
@@ -550,6 +565,7 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES, SEQ_WAVES / 2) lstm_seq_fwd_ke
         }
         if (!ok) {
           __hip_atomic_store((gu32_t*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicAdd(&g_seq_timeouts, 1u);
           s_abort = 1;
         }
       }
@@ -675,8 +691,7 @@ extern "C" int dvae_lstm_seq_fwd_f32(int64_t nchains, const float* const* xproj,
   const int groups = g.nchains * g.groups_per_chain;
   g.sync = (unsigned*)ws;
   g.xch = ws + SEQ_CNT_STRIDE * (1 + groups);
-  // arrival counters and the timeout word start every launch at zero
-  if (hipMemsetAsync(ws, 0, sizeof(unsigned) * SEQ_CNT_STRIDE * (1 + groups), ST(stream)) != hipSuccess) {
+  if (seq_clear(ws, groups, ST(stream)) != 0) {
     dvae_set_error("lstm_seq_fwd: clearing the counters failed: %s", hipGetErrorString(hipGetLastError()));
     return -EIO;
   }
@@ -747,6 +762,7 @@ __device__ __forceinline__ bool seq_wait(unsigned* cnt, unsigned* tmo, unsigned 
     }
     if (!ok) {
       __hip_atomic_store((gu32_t*)tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicAdd(&g_seq_timeouts, 1u);
       *s_abort = 1;
     }
   }
@@ -957,7 +973,7 @@ extern "C" int dvae_lstm_seq_bwd_f32(int64_t nchains, const float* const* w_rec,
   const int groups = g.nchains * g.groups_per_chain;
   g.sync = (unsigned*)ws;
   g.xch = ws + SEQ_CNT_STRIDE * (1 + groups);
-  if (hipMemsetAsync(ws, 0, sizeof(unsigned) * SEQ_CNT_STRIDE * (1 + groups), ST(stream)) != hipSuccess) {
+  if (seq_clear(ws, groups, ST(stream)) != 0) {
     dvae_set_error("lstm_seq_bwd: clearing the counters failed: %s", hipGetErrorString(hipGetLastError()));
     return -EIO;
   }
@@ -1177,7 +1193,7 @@ extern "C" int dvae_lstm_dec2_fwd_f32(const float* const* w_ih, const float* con
   g.groups = (int)ceil_div64(B, 32);
   g.sync = (unsigned*)ws;
   g.xch = ws + SEQ_CNT_STRIDE * (1 + g.groups);
-  if (hipMemsetAsync(ws, 0, sizeof(unsigned) * SEQ_CNT_STRIDE * (1 + g.groups), ST(stream)) != hipSuccess) {
+  if (seq_clear(ws, g.groups, ST(stream)) != 0) {
     dvae_set_error("lstm_dec2_fwd: clearing the counters failed: %s", hipGetErrorString(hipGetLastError()));
     return -EIO;
   }
@@ -1394,7 +1410,7 @@ extern "C" int dvae_lstm_dec2_bwd_f32(const float* const* w_ih, const float* con
   g.T = (int)T; g.B = B; g.groups = (int)ceil_div64(B, 32);
   g.sync = (unsigned*)ws;
   g.xch = ws + SEQ_CNT_STRIDE * (1 + g.groups);
-  if (hipMemsetAsync(ws, 0, sizeof(unsigned) * SEQ_CNT_STRIDE * (1 + g.groups), ST(stream)) != hipSuccess) {
+  if (seq_clear(ws, g.groups, ST(stream)) != 0) {
     dvae_set_error("lstm_dec2_bwd: clearing the counters failed: %s", hipGetErrorString(hipGetLastError()));
     return -EIO;
   }
@@ -1405,4 +1421,15 @@ extern "C" int dvae_lstm_dec2_bwd_f32(const float* const* w_ih, const float* con
   else DVAE_LAUNCH((lstm_dec_bwd_kernel<256>), dim3(nblocks), dim3(64 * SEQ_WAVES), 0, ST(stream), g);
   DVAE_LAUNCH_CHECK("lstm_dec2_bwd");
   return 0;
+}
+
+// Number of workgroups, on the current GPU and since the library was loaded, that gave up a bounded wait inside one
+// of the one-launch recurrence kernels (their outputs are then invalid).  Synchronises with the device.
+extern "C" int64_t dvae_lstm_seq_timeouts(void) {
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_seq_timeouts), sizeof(v), 0, hipMemcpyDeviceToHost) != hipSuccess) {
+    dvae_set_error("lstm_seq_timeouts: reading the counter failed: %s", hipGetErrorString(hipGetLastError()));
+    return -EIO;
+  }
+  return (int64_t)v;
 }

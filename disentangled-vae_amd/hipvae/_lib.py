@@ -96,6 +96,7 @@ SIGNATURES = {
     'dvae_lstm_seq_bwd_ws_floats': (L, [L, L, L]),
     'dvae_lstm_seq_bwd_f32': (I, [L] + [POINTER(c_void_p)] * 4 + [L, POINTER(c_void_p), L, L, POINTER(c_void_p),
                                   POINTER(c_void_p), L, POINTER(c_void_p), L, I, POINTER(c_int), L, L, L, P, P]),
+    'dvae_lstm_seq_timeouts': (L, []),
     'dvae_lstm_dec2_supported': (I, [L, L, L]),
     'dvae_lstm_dec2_ws_floats': (L, [L, L]),
     'dvae_lstm_dec2_fwd_f32': (I, [POINTER(c_void_p)] * 4 + [P, L, P, L, P, P, P, P, L, L, L, P, P]),

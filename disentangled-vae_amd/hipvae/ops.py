@@ -756,6 +756,23 @@ def lstm_seq_bwd(chains, T: int, B: int, H: int, accumulate_dh_init: bool = Fals
     return ws
 
 
+def lstm_seq_timeouts() -> int:
+    """Workgroups of the one-launch recurrence kernels that gave up a bounded wait on the current GPU since the
+    library was loaded (0 in a healthy run; the affected launches' outputs are invalid).  Synchronises."""
+    n = lib.dvae_lstm_seq_timeouts()
+    if n < 0:
+        check(int(n), 'lstm_seq_timeouts')
+    return int(n)
+
+
+def check_lstm_seq_timeouts():
+    n = lstm_seq_timeouts()
+    if n:
+        raise RuntimeError(f"{n} workgroup(s) of a one-launch LSTM kernel ran into the bound of a wait: the launch was "
+                           "not fully resident (another kernel held compute units for more than 200 ms); results of "
+                           "that step are invalid.  DVAE_SEQ_LSTM=0 selects one launch per step.")
+
+
 def lstm_dec2_supported(T: int, B: int, H: int) -> bool:
     return bool(lib.dvae_lstm_dec2_supported(T, B, H))
 

@@ -26,6 +26,7 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.optim as optim
 
+from hipvae import ops as hip_ops
 from hipvae.losses import baseline_loss, disentangled_loss, lstm_loss
 from hipvae.optim import FusedAdam
 from training.config import ExperimentConfig
@@ -305,6 +306,7 @@ class Trainer:
             self.global_step += 1
         if n == 0:
             return {}
+        hip_ops.check_lstm_seq_timeouts()      # (the read-back below synchronises anyway)
         out = self._unpack(last, self._rank_mean(acc / n).cpu())
         out['beta'] = beta
         return out

@@ -370,7 +370,7 @@ int dvae_skinny_gemm_nt_f32(const float* a, int64_t ld_a, const float* wt, int64
  *      All workgroups must be resident together, so dvae_lstm_seq_supported() admits H in {128, 256, 512}
  *      and nchains*ceil(B/32)*(H/8) <= 512 only; otherwise -EINVAL (use the per-step calls).
  *      ws: dvae_lstm_seq_ws_floats(nchains, B, H) floats, 256-byte aligned; ws[0] (read as unsigned) is
- *      non-zero after the launch if a wait inside it ran into its 40 ms bound (outputs are then invalid).
+ *      non-zero after the launch if a wait inside it ran into its 200 ms bound (outputs are then invalid).
  *      Not to be run concurrently with another launch of itself unless both fit the chip together. */
 int dvae_lstm_seq_supported(int64_t nchains, int64_t T, int64_t B, int64_t H);
 int64_t dvae_lstm_seq_ws_floats(int64_t nchains, int64_t B, int64_t H);
@@ -423,6 +423,11 @@ int dvae_lstm_dec2_bwd_f32(const float* const* w_ih, const float* const* w_hh, c
                            const float* c0, int64_t ld_c0, const float* dstates, int64_t ld_ds, int64_t step_ds,
                            float* dgates, float* dh0, int64_t ld_dh0, float* dc0, int64_t ld_dc0, float* dx0,
                            int64_t T, int64_t B, int64_t H, float* ws, dvae_stream_t stream);
+/* Every wait inside the one-launch recurrence kernels is bounded (200 ms: a workgroup that never becomes resident
+ * must not hang the GPU); a launch in which one ran out leaves invalid outputs.  Number of workgroups that gave up
+ * on the current GPU since the library was loaded; synchronises with the device, so call it where the caller
+ * synchronises anyway (end of an epoch, a logging interval). */
+int64_t dvae_lstm_seq_timeouts(void);
 
 /* ---- optimiser (torch.optim.Adam with L2 weight decay and nn.utils.clip_grad_norm_ as called at
  *      training/trainer.py:56-61,198-204).  Host arrays of n device pointers / sizes.

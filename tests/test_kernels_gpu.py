@@ -718,6 +718,11 @@ def test_lstm_dec2_bwd_stacked_decoder_in_one_launch(ops, T, B, H):
     assert torch.equal(first, dg)
 
 
+def test_lstm_seq_kernels_never_ran_into_a_wait_bound(ops):
+    """the per-GPU counter that outlives the launches (this module's LSTM tests have run before this one)"""
+    assert ops.lstm_seq_timeouts() == 0
+
+
 def test_lstm_seq_rejects_what_cannot_be_resident(ops):
     assert not ops.lstm_seq_supported(2, 19, 512, 256)           # 1024 workgroups
     assert not ops.lstm_seq_supported(1, 19, 32, 32)             # hidden size without a kernel

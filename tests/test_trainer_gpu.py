@@ -220,6 +220,55 @@ def test_trainer_with_graph_replay_matches_eager(tmp_path):
         np.testing.assert_allclose(graph[k], eager[k], rtol=1e-6, err_msg=k)
 
 
+@pytest.mark.parametrize('kind', ['disentangled', 'lstm'])
+def test_graph_replay_of_the_full_width_models_matches_eager(kind):
+    """The one-launch LSTM kernels (hidden size 256: encoder chains, single-layer and stacked decoder) only run at
+    the models' real widths.  Four replays of the captured step against four eager steps from the same state with
+    zero noise: same losses and parameters, and no workgroup of those kernels gave up a wait (under replay the
+    zeroing of their arrival counters must be ordered in front of them)."""
+    from hipvae import losses as L, ops, rng
+    from hipvae.graph import GraphedTrainStep
+    from hipvae.optim import FusedAdam
+    from models import get_model
+    orig = rng.draw_like
+    rng.draw_like = lambda t: torch.zeros_like(t)
+    try:
+        results = []
+        clips = [synthetic_clips(8, 20, 70 + i).cuda() for i in range(4)]
+        for use_graph in (False, True):
+            torch.manual_seed(11)
+            if kind == 'disentangled':
+                model = get_model('disentangled', sequence_length=20).cuda()
+                loss_of = lambda m, v: L.disentangled_loss(m(v), v, beta=4.0, recon_loss_type='bce',
+                                                           temporal_weight=0.05, independence_weight=0.02)
+            else:
+                model = get_model('lstm', sequence_length=20, lstm_layers=2, bidirectional=True).cuda()
+                loss_of = lambda m, v: (lambda o: L.lstm_loss(o[0], v, o[2], o[3], beta=1.0, recon_loss_type='bce'))(m(v))
+            opt = FusedAdam(model.parameters(), lr=1e-3)
+            losses = []
+            if use_graph:
+                g = GraphedTrainStep(model, opt, loss_of, clips[0], gradient_clip=5.0)
+                for v in clips:
+                    losses.append(float(g(v)['total_loss']))
+            else:
+                for v in clips:
+                    opt.zero_grad(set_to_none=True)
+                    ld = loss_of(model, v)
+                    ld['total_loss'].backward()
+                    opt.clip_grad_norm_(5.0)
+                    opt.step()
+                    losses.append(float(ld['total_loss']))
+            torch.cuda.synchronize()
+            results.append((losses, [p.detach().clone() for p in model.parameters()]))
+        assert ops.lstm_seq_timeouts() == 0
+        (le, pe), (lg, pg) = results
+        np.testing.assert_allclose(lg, le, rtol=2e-5)
+        for a, b in zip(pe, pg):
+            assert (a - b).abs().max().item() <= 1e-6 + 2e-4 * a.abs().max().item()
+    finally:
+        rng.draw_like = orig
+
+
 def _tiny_trainer_config(tmp_path, tag, num_epochs):
     from training.config import DataConfig, ExperimentConfig, ModelConfig, TrainingConfig
     info = json.load(open(os.path.join(GOLDEN, 'trainer_run.json')))
