@@ -57,6 +57,17 @@ USE_OFF_PATH = os.environ.get('DVAE_OFF_PATH', '0') == '1'
 _OFF_STREAMS = {}
 
 
+def _seq_ok(chains: int, T: int, B: int, H: int) -> bool:
+    """Whether a recurrence runs as one launch.  Every workgroup of such a launch must become resident: with
+    several ranks the collectives' kernels share the compute units with the backward pass, so only grids of at
+    most one workgroup per compute unit are used there (single process: up to two)."""
+    if not (USE_SEQ_KERNELS and ops.lstm_seq_supported(chains, T, B, H)):
+        return False
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        return chains * ((B + 31) // 32) * (H // 8) <= 256
+    return True
+
+
 class _OffPath:
     """Inside one backward node: work whose result only the optimiser needs (weight gradients, their slab
     reductions and re-orderings) is issued on a second stream, so that it runs beside the chain of data
@@ -435,7 +446,7 @@ class LSTMEncoder(torch.autograd.Function):
             ws = [[w.detach() for w in weights[(l * D + d) * 4:(l * D + d) * 4 + 4]] for d in range(D)]
             xproj = [ops.gemm_nt(inp.view(T * B, I), ws[d][0].contiguous()).view(T, B, 4 * H) for d in range(D)]
             w_hh = [ws[d][1].contiguous() for d in range(D)]
-            if USE_SEQ_KERNELS and ops.lstm_seq_supported(D, T, B, H):
+            if _seq_ok(D, T, B, H):
                 # the whole recurrence of both directions in one launch, recurrent weights in registers
                 ops.lstm_seq_fwd([dict(xproj=xproj[d], w_rec=w_hh[d], b_a=ws[d][2].contiguous(),
                                        b_b=ws[d][3].contiguous(), gates=gates[d],
@@ -486,7 +497,7 @@ class LSTMEncoder(torch.autograd.Function):
             dgs = [_empty(T, B, 4 * H, like=dfinal) for _ in range(D)]
             dcs = [[_empty(B, H, like=dfinal), _empty(B, H, like=dfinal)] for _ in range(D)]
             w_hhs = [weights[(l * D + d) * 4 + 1].contiguous() for d in range(D)]
-            seq = USE_SEQ_KERNELS and ops.lstm_seq_supported(D, T, B, H)
+            seq = _seq_ok(D, T, B, H)
             if seq:
                 # both directions' chains in one launch, recurrent weights in registers
                 ops.lstm_seq_bwd([dict(w_rec=w_hhs[d], gates=gates[d], cseq=cseq[d],
@@ -566,7 +577,7 @@ class LSTMDecoder(torch.autograd.Function):
         # a single layer is fed its own previous output: x_t == h_{t-1} for t > 0, so
         # x W_ih^T + h W_hh^T = h (W_ih + W_hh)^T and the step is H deep instead of 2H
         w_comb = (w[0] + w[1]) if (L == 1 and T > 1) else None
-        seq = w_comb is not None and USE_SEQ_KERNELS and ops.lstm_seq_supported(1, T - 1, B, H)
+        seq = w_comb is not None and _seq_ok(1, T - 1, B, H)
         dec2 = L == 2 and USE_SEQ_KERNELS and ops.lstm_dec2_supported(T, B, H)
         if dec2:
             # both layers' cells of all T steps as one chain in one launch, the four weight slices in registers
@@ -621,7 +632,7 @@ class LSTMDecoder(torch.autograd.Function):
         w_ih_t = [weights[4 * l].t().contiguous() for l in range(L)]
         w_hh_t = [weights[4 * l + 1].t().contiguous() for l in range(L)]
         fused = L == 1 and T > 1          # single layer: one launch per step (product + next pointwise) ...
-        seq = fused and USE_SEQ_KERNELS and ops.lstm_seq_supported(1, T - 1, B, H)   # ... or one for all of them
+        seq = fused and _seq_ok(1, T - 1, B, H)   # ... or one for all of them
         w_comb_t = (w_ih_t[0] + w_hh_t[0]) if (fused and not seq) else None
         if seq:
             # steps T-1 .. 1 in one launch (W_ih + W_hh in registers); it leaves dL/dh_0 and dL/dc_0 for step 0
