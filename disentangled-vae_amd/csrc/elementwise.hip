@@ -347,39 +347,60 @@ __device__ __forceinline__ float recon_grad_elem(float r, float x, int kind) {
   return (r - x) / fmaxf((1.f - r) * r, 1e-12f);
 }
 
+__global__ void sum_partials_kernel(const double* __restrict__ partials, int n, float* out);   // defined below
+
+// LOGIT: the reconstruction is the sigmoid output of the decoder's last layer and the caller wants the gradient
+// with respect to that layer's pre-activation: every element is multiplied by r(1-r) on its way out (the same
+// float operations, in the same order, as a separate sigmoid-backward pass over the stored gradient), and the
+// workgroup's sum of what it wrote goes to partials[blockIdx.x] (the last layer's bias gradient).
+template <bool LOGIT>
 __global__ void __launch_bounds__(256)
 recon_loss_bwd_kernel(const float4* __restrict__ recon, const float4* __restrict__ target,
                       const float* __restrict__ gscale, float4* __restrict__ drecon, int64_t total, int T,
-                      int64_t P4, int kind, float w_rec, float w_tmp) {
+                      int64_t P4, int kind, float w_rec, float w_tmp, double* __restrict__ partials) {
+  __shared__ double red[4];
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const float g = gscale ? gscale[0] : 1.f;
-  const float wr = w_rec * g, wt = w_tmp * g;
-  const int64_t b = idx / P4, p = idx - b * P4;
-  const float4* r = recon + b * T * P4 + p;
-  const float4* x = target + b * T * P4 + p;
-  float4* d = drecon + b * T * P4 + p;
-  float4 rc = r[0], xc = x[0];
-  float4 dprev = make_float4(0.f, 0.f, 0.f, 0.f);  // (dr - dx) between t-1 and t
-  for (int t = 0; t < T; ++t) {
-    float4 rn = rc, xn = xc;
-    float4 dnext = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t + 1 < T) {
-      rn = r[(int64_t)(t + 1) * P4];
-      xn = x[(int64_t)(t + 1) * P4];
-      if (wt != 0.f)
-        dnext = make_float4((rn.x - rc.x) - (xn.x - xc.x), (rn.y - rc.y) - (xn.y - xc.y),
-                            (rn.z - rc.z) - (xn.z - xc.z), (rn.w - rc.w) - (xn.w - xc.w));
+  double sum = 0.0;
+  if (idx < total) {
+    const float g = gscale ? gscale[0] : 1.f;
+    const float wr = w_rec * g, wt = w_tmp * g;
+    const int64_t b = idx / P4, p = idx - b * P4;
+    const float4* r = recon + b * T * P4 + p;
+    const float4* x = target + b * T * P4 + p;
+    float4* d = drecon + b * T * P4 + p;
+    float4 rc = r[0], xc = x[0];
+    float4 dprev = make_float4(0.f, 0.f, 0.f, 0.f);  // (dr - dx) between t-1 and t
+    for (int t = 0; t < T; ++t) {
+      float4 rn = rc, xn = xc;
+      float4 dnext = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t + 1 < T) {
+        rn = r[(int64_t)(t + 1) * P4];
+        xn = x[(int64_t)(t + 1) * P4];
+        if (wt != 0.f)
+          dnext = make_float4((rn.x - rc.x) - (xn.x - xc.x), (rn.y - rc.y) - (xn.y - xc.y),
+                              (rn.z - rc.z) - (xn.z - xc.z), (rn.w - rc.w) - (xn.w - xc.w));
+      }
+      float4 o;
+      o.x = wr * recon_grad_elem(rc.x, xc.x, kind) + wt * (dprev.x - dnext.x);
+      o.y = wr * recon_grad_elem(rc.y, xc.y, kind) + wt * (dprev.y - dnext.y);
+      o.z = wr * recon_grad_elem(rc.z, xc.z, kind) + wt * (dprev.z - dnext.z);
+      o.w = wr * recon_grad_elem(rc.w, xc.w, kind) + wt * (dprev.w - dnext.w);
+      if (LOGIT) {
+        o.x = o.x * rc.x * (1.f - rc.x);
+        o.y = o.y * rc.y * (1.f - rc.y);
+        o.z = o.z * rc.z * (1.f - rc.z);
+        o.w = o.w * rc.w * (1.f - rc.w);
+        sum += ((double)o.x + (double)o.y) + ((double)o.z + (double)o.w);
+      }
+      d[(int64_t)t * P4] = o;
+      dprev = dnext;
+      rc = rn;
+      xc = xn;
     }
-    float4 o;
-    o.x = wr * recon_grad_elem(rc.x, xc.x, kind) + wt * (dprev.x - dnext.x);
-    o.y = wr * recon_grad_elem(rc.y, xc.y, kind) + wt * (dprev.y - dnext.y);
-    o.z = wr * recon_grad_elem(rc.z, xc.z, kind) + wt * (dprev.z - dnext.z);
-    o.w = wr * recon_grad_elem(rc.w, xc.w, kind) + wt * (dprev.w - dnext.w);
-    d[(int64_t)t * P4] = o;
-    dprev = dnext;
-    rc = rn;
-    xc = xn;
+  }
+  if (LOGIT) {
+    sum = block_sum_256(sum, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = sum;
   }
 }
 
@@ -393,10 +414,37 @@ extern "C" int dvae_recon_loss_bwd_f32(const float* recon, const float* target, 
   const float w_rec = 1.f / (float)B;
   const float w_tmp = (T > 1) ? 2.f * temporal_weight / (float)B : 0.f;
   DVAE_WORK(12.0 * (double)B * T * P, DVAE_UNIT_BYTE);                     // recon, target in; gradient out
-  DVAE_LAUNCH(recon_loss_bwd_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, ST(stream),
+  DVAE_LAUNCH(recon_loss_bwd_kernel<false>, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, ST(stream),
                      (const float4*)recon, (const float4*)target, gscale, (float4*)drecon, total, (int)T, P / 4,
-                     kind, w_rec, w_tmp);
+                     kind, w_rec, w_tmp, (double*)nullptr);
   DVAE_LAUNCH_CHECK("recon_loss_bwd");
+  return 0;
+}
+
+extern "C" int64_t dvae_recon_loss_bwd_logit_ws_floats(int64_t B, int64_t P) {
+  return 2 * ceil_div64(B * (P / 4), 256);      // one double per workgroup
+}
+
+extern "C" int dvae_recon_loss_bwd_logit_f32(const float* recon, const float* target, const float* gscale,
+                                             float* dlogit, float* dbias, float* ws, int64_t B, int64_t T, int64_t P,
+                                             int kind, float temporal_weight, dvae_stream_t stream) {
+  DVAE_REQUIRE(B > 0 && T >= 1 && P > 0 && P % 4 == 0, "recon_loss_bwd_logit: need P%%4==0");
+  DVAE_REQUIRE(kind == 0 || kind == 1, "recon_loss_bwd_logit: kind must be 0 (mse) or 1 (bce)");
+  DVAE_REQUIRE(ws != nullptr && ((uintptr_t)ws & 7) == 0, "recon_loss_bwd_logit: workspace must be 8-byte aligned");
+  const int64_t total = B * (P / 4);
+  const int64_t nb = ceil_div64(total, 256);
+  DVAE_REQUIRE(nb < (int64_t)1 << 31, "recon_loss_bwd_logit: too many elements");
+  const float w_rec = 1.f / (float)B;
+  const float w_tmp = (T > 1) ? 2.f * temporal_weight / (float)B : 0.f;
+  DVAE_WORK(12.0 * (double)B * T * P, DVAE_UNIT_BYTE);
+  DVAE_LAUNCH(recon_loss_bwd_kernel<true>, dim3((unsigned)nb), dim3(256), 0, ST(stream), (const float4*)recon,
+                     (const float4*)target, gscale, (float4*)dlogit, total, (int)T, P / 4, kind, w_rec, w_tmp,
+                     (double*)ws);
+  DVAE_LAUNCH_CHECK("recon_loss_bwd_logit");
+  if (dbias) {
+    DVAE_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, ST(stream), (const double*)ws, (int)nb, dbias);
+    DVAE_LAUNCH_CHECK("recon_loss_bwd_logit_sum");
+  }
   return 0;
 }
 

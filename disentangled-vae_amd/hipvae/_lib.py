@@ -37,6 +37,8 @@ SIGNATURES = {
     'dvae_recon_metrics_noalloc_max_elements': (L, []),
     'dvae_recon_metrics_noalloc_f32': (I, [P, P, P, L, L, L, F, P]),
     'dvae_recon_loss_bwd_f32': (I, [P, P, P, P, L, L, L, I, F, P]),
+    'dvae_recon_loss_bwd_logit_ws_floats': (L, [L, L]),
+    'dvae_recon_loss_bwd_logit_f32': (I, [P, P, P, P, P, P, L, L, L, I, F, P]),
     'dvae_reparam_fwd_f32': (I, [P, P, P, P, L, P]),
     'dvae_reparam_bwd_f32': (I, [P, P, P, P, P, L, P]),
     'dvae_kl_fwd_f32': (I, [P, P, P, L, L, F, P]),

@@ -213,6 +213,40 @@ class EncoderCNN(torch.autograd.Function):
 
 
 # =================================================================================================
+class SigmoidTail:
+    """Hand-off between the decoder's last layer and a loss node that consumes its output directly.
+
+    The reconstruction leaves DecoderCNN through a sigmoid, and the loss's gradient pass reads the reconstruction
+    anyway, so it can write d/d(logit) = d/d(recon) * recon * (1 - recon) at once and save the separate pass over
+    three clip-sized tensors.  The decoder attaches one of these records to the tensor it returns (`as_clips`
+    carries it onto the [B, T, ...] view); a loss node that finds it writes the logit-form gradient, notes the
+    tensor here and returns it as its gradient; DecoderCNN.backward recognises its own record's tensor by address.
+    Any other gradient that autograd adds on the way (the reconstruction used twice) arrives as a different
+    tensor and is corrected for, so the result is the same whichever path runs."""
+    __slots__ = ('dlogit', 'dbias')
+
+    def __init__(self):
+        self.dlogit: Optional[Tensor] = None
+        self.dbias: Optional[Tensor] = None
+
+
+FUSE_TAIL = os.environ.get('DVAE_FUSE_TAIL', '1') != '0'
+
+
+def sigmoid_tail(recon: Tensor) -> Optional[SigmoidTail]:
+    """The hand-off record of a reconstruction that came straight from DecoderCNN (None otherwise)."""
+    return getattr(recon, '_dvae_tail', None) if FUSE_TAIL else None
+
+
+def as_clips(frames: Tensor, B: int, T: int) -> Tensor:
+    """[B*T, C, H, W] frames of DecoderCNN as [B, T, C, H, W] clips, keeping the hand-off record."""
+    clips = frames.view(B, T, *frames.shape[1:])
+    tail = getattr(frames, '_dvae_tail', None)
+    if tail is not None:
+        clips._dvae_tail = tail
+    return clips
+
+
 class DecoderCNN(torch.autograd.Function):
     """CNNDecoder of the reference (models/decoders.py:11-70); returns frames [N, 1, 2^k*4, ...]."""
 
@@ -253,6 +287,7 @@ class DecoderCNN(torch.autograd.Function):
             ctx.gammas = [g.detach() for g in gammas]
             ctx.L = L
             ctx.dims = (C0, S, Kin)
+            ctx.tail = recon._dvae_tail = SigmoidTail()
         else:
             ctx.L = -1
         return recon
@@ -269,7 +304,18 @@ class DecoderCNN(torch.autograd.Function):
         C0, S, Kin = ctx.dims
         N = feat.shape[0]
         off = _OffPath(drecon)
-        dlogit, d_final_b = ops.sigmoid_bwd(drecon.contiguous(), recon)
+        tail, fused = ctx.tail, None
+        if tail.dlogit is not None:
+            fused, fused_b = tail.dlogit, tail.dbias
+            tail.dlogit = tail.dbias = None
+        if fused is not None and drecon.data_ptr() == fused.data_ptr() and drecon.numel() == fused.numel():
+            dlogit, d_final_b = fused.view_as(recon), fused_b          # the loss node wrote d/d(logit) already
+        elif fused is not None:
+            # the loss node's logit-form gradient plus gradients of other consumers of the reconstruction
+            rest, rest_b = ops.sigmoid_bwd((drecon - fused.view_as(drecon)).contiguous().view_as(recon), recon)
+            dlogit, d_final_b = rest + fused.view_as(recon), rest_b + fused_b
+        else:
+            dlogit, d_final_b = ops.sigmoid_bwd(drecon.contiguous(), recon)
         Ho, Wo = recon.shape[2], recon.shape[3]
         dlogit4 = dlogit.view(N, Ho, Wo, 1)
         # input of the final layer: last raw deconv output with its BN+LReLU, or h0 itself when L == 0

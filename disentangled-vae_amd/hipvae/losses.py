@@ -10,9 +10,20 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
+from .functional import sigmoid_tail
 
 Tensor = torch.Tensor
 _KIND = {'mse': 0, 'bce': 1}
+
+
+def _recon_grad(tail, recon, target, gs, kind, tw):
+    """Gradient of the reconstruction terms: in logit form, handed to the decoder that produced `recon`, when that
+    decoder left a hand-off record and nobody has used it yet in this backward pass (see functional.SigmoidTail)."""
+    if tail is not None and tail.dlogit is None:
+        d, db = ops.recon_loss_bwd_logit(recon, target, gs, kind, tw)
+        tail.dlogit, tail.dbias = d, db
+        return d
+    return ops.recon_loss_bwd(recon, target, gs, kind, tw)
 
 
 class LossDict(dict):
@@ -43,7 +54,7 @@ class _DisentangledLoss(torch.autograd.Function):
     # (mean, raw, per-dim), 8..10 motion KL, 11 independence.  Two outputs: the packed values (reporting only) and
     # the total as a tensor of its own, which is what carries the gradient.
     @staticmethod
-    def forward(ctx, recon, target, mu_c, lv_c, mu_m, lv_m, z_c, z_m, beta_c, beta_m, kind, tw, iw):
+    def forward(ctx, recon, target, mu_c, lv_c, mu_m, lv_m, z_c, z_m, beta_c, beta_m, kind, tw, iw, tail):
         recon, target = recon.contiguous(), target.contiguous()
         mu_c, lv_c, mu_m, lv_m = [t.contiguous() for t in (mu_c, lv_c, mu_m, lv_m)]
         vals = torch.empty(12, dtype=torch.float32, device=recon.device)
@@ -58,6 +69,7 @@ class _DisentangledLoss(torch.autograd.Function):
         ctx.save_for_backward(recon, target, mu_c, lv_c, mu_m, lv_m, z_c if iw > 0 else None,
                               z_m if iw > 0 else None, ws)
         ctx.cfg = (beta_c, beta_m, kind, tw, iw)
+        ctx.tail = tail
         ctx.mark_non_differentiable(vals)
         return vals, total.view(())
 
@@ -67,13 +79,13 @@ class _DisentangledLoss(torch.autograd.Function):
         beta_c, beta_m, kind, tw, iw = ctx.cfg
         gs = g.reshape(1).contiguous()                             # d/d total_loss, a device scalar
         need = ctx.needs_input_grad
-        drecon = ops.recon_loss_bwd(recon, target, gs, kind, tw) if need[0] else None
+        drecon = _recon_grad(ctx.tail, recon, target, gs, kind, tw) if need[0] else None
         dmu_c = dlv_c = dmu_m = dlv_m = dz_c = dz_m = None
         if need[2] or need[3] or need[4] or need[5]:
             (dmu_c, dlv_c), (dmu_m, dlv_m) = ops.kl_bwd2([(mu_c, lv_c, beta_c), (mu_m, lv_m, beta_m)], gs, 0.0)
         if iw > 0 and (need[6] or need[7]):
             dz_c, dz_m = ops.indep_bwd(z_c, z_m, ws, gs, iw)
-        return (drecon, None, dmu_c, dlv_c, dmu_m, dlv_m, dz_c, dz_m, None, None, None, None, None)
+        return (drecon, None, dmu_c, dlv_c, dmu_m, dlv_m, dz_c, dz_m, None, None, None, None, None, None)
 
 
 def disentangled_loss(output: Dict[str, Tensor], target: Tensor, beta: float = 1.0,
@@ -87,7 +99,7 @@ def disentangled_loss(output: Dict[str, Tensor], target: Tensor, beta: float = 1
     v, total = _DisentangledLoss.apply(output['recon'], target, output['mu_content'], output['logvar_content'],
                                        output['mu_motion'], output['logvar_motion'], output['z_content'],
                                        output['z_motion'], float(bc), float(bm), kind, float(temporal_weight),
-                                       float(independence_weight))
+                                       float(independence_weight), sigmoid_tail(output['recon']))
     return LossDict(v, {'total_loss': 0, 'recon_loss': 3, 'recon_loss_per_pixel': 2, 'kl_loss': 1,
                         'kl_content': 5, 'kl_motion': 8, 'temporal_loss': 4, 'independence_loss': 11}, beta, total)
 
@@ -95,13 +107,14 @@ def disentangled_loss(output: Dict[str, Tensor], target: Tensor, beta: float = 1
 class _TupleLoss(torch.autograd.Function):
     # values layout: 0 total, 1 recon_per_pixel, 2 recon_scaled, 3 temporal, 4 kl, 5 kl_raw, 6 kl_per_dim
     @staticmethod
-    def forward(ctx, recon, target, mu, logvar, beta, kind, tw, free_bits):
+    def forward(ctx, recon, target, mu, logvar, beta, kind, tw, free_bits, tail):
         recon, target, mu, logvar = [t.contiguous() for t in (recon, target, mu, logvar)]
         vals = torch.empty(7, dtype=torch.float32, device=recon.device)
         total = torch.empty(1, dtype=torch.float32, device=recon.device)
         ops.vae_loss_fwd(recon, target, kind, tw > 0, [(mu, logvar, beta)], free_bits, tw, None, 0.0, vals, total)
         ctx.save_for_backward(recon, target, mu, logvar)
         ctx.cfg = (beta, kind, tw, free_bits)
+        ctx.tail = tail
         ctx.mark_non_differentiable(vals)
         return vals, total.view(())
 
@@ -111,17 +124,18 @@ class _TupleLoss(torch.autograd.Function):
         beta, kind, tw, free_bits = ctx.cfg
         gs = g.reshape(1).contiguous()
         need = ctx.needs_input_grad
-        drecon = ops.recon_loss_bwd(recon, target, gs, kind, tw) if need[0] else None
+        drecon = _recon_grad(ctx.tail, recon, target, gs, kind, tw) if need[0] else None
         dmu = dlv = None
         if need[2] or need[3]:
             dmu, dlv = ops.kl_bwd(mu, logvar, gs, beta, free_bits)
-        return drecon, None, dmu, dlv, None, None, None, None
+        return drecon, None, dmu, dlv, None, None, None, None, None
 
 
 def _tuple_loss(recon, target, mu, logvar, beta, recon_loss_type, temporal_weight, free_bits, use_free_bits):
     kind = _kind(recon_loss_type)
     fb = float(free_bits) if (use_free_bits and free_bits > 0) else 0.0
-    return _TupleLoss.apply(recon, target, mu, logvar, float(beta), kind, float(temporal_weight), fb)
+    return _TupleLoss.apply(recon, target, mu, logvar, float(beta), kind, float(temporal_weight), fb,
+                            sigmoid_tail(recon))
 
 
 def lstm_loss(recon, target, mu, logvar, beta: float = 1.0, recon_loss_type: str = 'mse',

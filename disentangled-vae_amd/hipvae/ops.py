@@ -145,6 +145,20 @@ def recon_loss_bwd(recon: Tensor, target: Tensor, gscale: Optional[Tensor], kind
     return d
 
 
+def recon_loss_bwd_logit(recon: Tensor, target: Tensor, gscale: Optional[Tensor], kind: int,
+                         temporal_weight: float):
+    """recon_loss_bwd taken through the sigmoid that produced `recon`, in one pass: (dlogit, dbias)."""
+    _chk(recon, target, gscale)
+    B, T = recon.shape[:2]
+    P = recon[0, 0].numel()
+    d = torch.empty_like(recon)
+    db = torch.empty(1, dtype=torch.float32, device=recon.device)
+    ws = workspace(lib.dvae_recon_loss_bwd_logit_ws_floats(B, P), recon.device)
+    check(lib.dvae_recon_loss_bwd_logit_f32(_p(recon), _p(target), _p(gscale), _p(d), _p(db), _p(ws), B, T, P, kind,
+                                            float(temporal_weight), _stream()), 'recon_loss_bwd_logit')
+    return d, db
+
+
 def reparam_fwd(mu, logvar, eps):
     _chk(mu, logvar, eps)
     z = torch.empty_like(mu)

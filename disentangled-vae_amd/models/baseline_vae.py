@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from hipvae.losses import baseline_loss as compute_loss  # noqa: F401  (reference name)
+from hipvae import functional as HF
 from hipvae.parallel import stage_boundary
 from .decoders import CNNDecoder
 from .encoders import CNNEncoder, VAEEncoder, reparameterize
@@ -39,7 +40,7 @@ class BaselineVAE(nn.Module):
         T = sequence_length or self.sequence_length
         zf = z.unsqueeze(1).expand(-1, T, -1).reshape(B * T, -1)
         frames = self.cnn_decoder(zf)
-        return frames.view(B, T, *frames.shape[1:])
+        return HF.as_clips(frames, B, T)
 
     def forward(self, video: torch.Tensor):
         z, mu, logvar = self.encode(video)

@@ -105,7 +105,7 @@ class VideoDecoder(nn.Module):
         if self.use_content_modulation and z_content is not None:
             ff = torch.cat([ff, z_content.unsqueeze(1).expand(-1, T, -1)], dim=-1)
         frames = self.cnn_decoder(ff.reshape(B * T, -1))
-        return frames.view(B, T, *frames.shape[1:])
+        return HF.as_clips(frames, B, T)
 
 
 class DisentangledDecoder(nn.Module):
@@ -139,4 +139,4 @@ class DisentangledDecoder(nn.Module):
         ff = HF.linear(states, self.fc_frame[0].weight, self.fc_frame[0].bias, ops.ACT_LRELU)
         ff = torch.cat([ff, z_content.unsqueeze(1).expand(-1, T, -1)], dim=-1)
         frames = self.cnn_decoder(ff.reshape(B * T, -1))
-        return frames.view(B, T, *frames.shape[1:])
+        return HF.as_clips(frames, B, T)

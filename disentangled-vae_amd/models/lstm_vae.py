@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from hipvae.losses import lstm_loss as compute_loss  # noqa: F401  (reference name)
+from hipvae import functional as HF
 from hipvae.parallel import stage_boundary
 from .decoders import CNNDecoder, LSTMDecoder
 from .encoders import CNNEncoder, LSTMEncoder, VAEEncoder, reparameterize
@@ -43,7 +44,7 @@ class LSTMVAE(nn.Module):
         T = sequence_length or self.sequence_length
         ff = self.lstm_decoder(z, sequence_length=T)
         frames = self.cnn_decoder(ff.reshape(B * T, -1))
-        return frames.view(B, T, *frames.shape[1:])
+        return HF.as_clips(frames, B, T)
 
     def forward(self, video: torch.Tensor):
         z, mu, logvar = self.encode(video)

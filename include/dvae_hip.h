@@ -76,6 +76,14 @@ int dvae_recon_loss_fwd_f32(const float* recon, const float* target, float* out,
 int dvae_recon_loss_bwd_f32(const float* recon, const float* target, const float* gscale, float* drecon,
                             int64_t B, int64_t T, int64_t P, int kind, float temporal_weight,
                             dvae_stream_t stream);
+/* The same gradient taken through the sigmoid that produced recon (models/decoders.py:67-68: the decoder's
+ * output activation): dlogit = [d.../d recon] * recon * (1 - recon), written in one pass instead of a gradient pass
+ * followed by a sigmoid-backward pass over it, and *dbias = sum(dlogit), the gradient of the final transposed
+ * convolution's bias (dbias may be NULL).  ws: dvae_recon_loss_bwd_logit_ws_floats(B,P) floats, 8-byte aligned. */
+int64_t dvae_recon_loss_bwd_logit_ws_floats(int64_t B, int64_t P);
+int dvae_recon_loss_bwd_logit_f32(const float* recon, const float* target, const float* gscale, float* dlogit,
+                                  float* dbias, float* ws, int64_t B, int64_t T, int64_t P, int kind,
+                                  float temporal_weight, dvae_stream_t stream);
 
 /* ---- reconstruction metrics of the evaluation loop in one pass (evaluation/metrics.py:14-22 mse and
  *      psnr, :48-50 temporal_consistency; called per batch from reconstruction_metrics, :80-83).

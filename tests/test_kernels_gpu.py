@@ -1060,3 +1060,19 @@ def test_evaluation_metrics_module(ops):
     v = batches[0][0]
     assert abs(M.temporal_consistency(v.cuda()) - O.recon_metrics(v.double(), v.double())[2]) <= 1e-6
     assert M.psnr(v.cuda(), v.cuda()) == float('inf')
+
+
+@pytest.mark.parametrize('kind,tw', [(0, 0.0), (0, 0.5), (1, 0.0), (1, 0.25)])
+@pytest.mark.parametrize('B,T,P', [(3, 5, 64 * 64), (2, 1, 128), (5, 7, 36)])
+def test_recon_gradient_in_logit_form_is_the_two_pass_result(ops, kind, tw, B, T, P):
+    torch.manual_seed(11)
+    recon = torch.sigmoid(3 * torch.randn(B, T, P, device='cuda'))
+    target = torch.rand(B, T, P, device='cuda')
+    gs = torch.tensor([0.37], device='cuda')
+    d = ops.recon_loss_bwd(recon, target, gs, kind, tw)
+    want, want_b = ops.sigmoid_bwd(d, recon)
+    got, got_b = ops.recon_loss_bwd_logit(recon, target, gs, kind, tw)
+    assert torch.equal(got, want)
+    ref_b = want.double().sum().item()
+    assert abs(got_b.item() - ref_b) <= 1e-5 * max(abs(ref_b), want.double().abs().sum().item() * 1e-2)
+    assert abs(want_b.item() - ref_b) <= 1e-5 * max(abs(ref_b), want.double().abs().sum().item() * 1e-2)

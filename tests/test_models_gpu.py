@@ -126,6 +126,56 @@ def test_train_step_matches_reference_vectors(kind):
             assert np.array_equal(v.cpu().numpy(), ref), k
 
 
+def _grads_of_step(kind, extra=None, fuse=True):
+    """Parameter gradients of one training step on the golden inputs; `extra(recon)` adds a second consumer of the
+    reconstruction to the objective."""
+    from hipvae import functional as HF, rng
+    g = load_step(kind)
+    m = build(kind, g).train()
+    video = torch.from_numpy(g['video']).cuda()
+    eps = [torch.from_numpy(g[f'eps{k}']) for k in range(2) if f'eps{k}' in g]
+    from hipvae import ops
+    calls = []
+    plain = ops.sigmoid_bwd
+    old, HF.FUSE_TAIL = HF.FUSE_TAIL, fuse
+    ops.sigmoid_bwd = lambda *a, **k: (calls.append(1), plain(*a, **k))[1]
+    try:
+        with rng.inject_eps(eps):
+            out = m(video)
+        total = loss_of(kind, out, video, SETTINGS['tcfg'][kind], SETTINGS['beta'])['total_loss']
+        if extra is not None:
+            total = total + extra(as_dict(kind, out)['recon'])
+        total.backward()
+    finally:
+        HF.FUSE_TAIL = old
+        ops.sigmoid_bwd = plain
+    # the separate sigmoid-backward pass runs exactly when the one-pass path does not cover the whole gradient
+    assert len(calls) == (0 if fuse and extra is None else 1)
+    return {n: p.grad.clone() for n, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize('kind', ['disentangled', 'lstm', 'baseline'])
+def test_logit_form_loss_gradient_gives_the_gradients_of_the_two_pass_path(kind):
+    # the loss node writes d/d(logit) straight into the decoder's hands (one pass) or d/d(recon) followed by the
+    # decoder's own sigmoid backward (two passes): the same float operations, so the same bits, except for the
+    # final layer's bias gradient (a sum taken in a different order)
+    one, two = _grads_of_step(kind, fuse=True), _grads_of_step(kind, fuse=False)
+    for n in one:
+        if n.endswith('final.bias'):
+            assert rel(one[n].cpu().numpy(), two[n].cpu().numpy()) < 1e-5, n
+        else:
+            assert torch.equal(one[n], two[n]), n
+
+
+def test_a_second_consumer_of_the_reconstruction_is_added_correctly_to_the_logit_form_gradient():
+    # autograd then hands the decoder (logit-form gradient of the loss) + (plain gradient of the other term)
+    w = torch.linspace(-1.0, 1.0, 64, device='cuda').view(1, 1, 1, 1, 64)
+    extra = lambda recon: 37.0 * (recon * w).sum() + 5.0 * (recon * recon).sum()   # noqa: E731
+    one, two = _grads_of_step('disentangled', extra, fuse=True), _grads_of_step('disentangled', extra, fuse=False)
+    for n in one:
+        assert rel(one[n].cpu().numpy(), two[n].cpu().numpy()) < 2e-5, (n, rel(one[n].cpu().numpy(), two[n].cpu().numpy()))
+
+
 FULL = {
     'disentangled': dict(content_dim=128, motion_dim=128, content_channels=[32, 64, 128, 256],
                          motion_channels=[16, 32], decoder_channels=[256, 128, 64, 32], content_feature_dim=512,
