@@ -872,7 +872,7 @@ extern "C" int dvae_indep_bwd_f32(const float* zc, const float* zm, const float*
 // BatchNorm glue
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-bn_finalize_kernel(const float* __restrict__ partials, int64_t nparts, double M, int64_t C,
+bn_finalize_kernel(const float* __restrict__ partials, int64_t nparts, double M, double Mrep, int64_t C,
                    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                    float* running_var, int64_t* nbt, float momentum, float eps, float* scale, float* shift,
                    float* mean_out, float* invstd_out) {
@@ -896,7 +896,7 @@ bn_finalize_kernel(const float* __restrict__ partials, int64_t nparts, double M,
     mean_out[c] = (float)mean;
     invstd_out[c] = (float)invstd;
     if (running_mean) {
-      const double unb = M > 1.0 ? var * (M / (M - 1.0)) : var;
+      const double unb = Mrep > 1.0 ? var * (Mrep / (Mrep - 1.0)) : var;
       running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
       running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
     }
@@ -904,17 +904,25 @@ bn_finalize_kernel(const float* __restrict__ partials, int64_t nparts, double M,
   }
 }
 
+extern "C" int dvae_bn_finalize_rep_f32(const float* partials, int64_t nparts, int64_t M, int64_t replicas, int64_t C,
+                                        const float* gamma, const float* beta, float* running_mean,
+                                        float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                                        float* scale, float* shift, float* mean, float* invstd, dvae_stream_t stream) {
+  DVAE_REQUIRE(nparts > 0 && M > 0 && C > 0 && replicas >= 1, "bn_finalize: empty");
+  DVAE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running buffers come in pairs");
+  DVAE_LAUNCH(bn_finalize_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), partials, nparts, (double)M,
+                     (double)M * (double)replicas, C, gamma, beta, running_mean, running_var, num_batches_tracked,
+                     momentum, eps, scale, shift, mean, invstd);
+  DVAE_LAUNCH_CHECK("bn_finalize");
+  return 0;
+}
+
 extern "C" int dvae_bn_finalize_f32(const float* partials, int64_t nparts, int64_t M, int64_t C, const float* gamma,
                                     const float* beta, float* running_mean, float* running_var,
                                     int64_t* num_batches_tracked, float momentum, float eps, float* scale,
                                     float* shift, float* mean, float* invstd, dvae_stream_t stream) {
-  DVAE_REQUIRE(nparts > 0 && M > 0 && C > 0, "bn_finalize: empty");
-  DVAE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running buffers come in pairs");
-  DVAE_LAUNCH(bn_finalize_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), partials, nparts, (double)M, C,
-                     gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean,
-                     invstd);
-  DVAE_LAUNCH_CHECK("bn_finalize");
-  return 0;
+  return dvae_bn_finalize_rep_f32(partials, nparts, M, 1, C, gamma, beta, running_mean, running_var,
+                                  num_batches_tracked, momentum, eps, scale, shift, mean, invstd, stream);
 }
 
 __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,

@@ -52,6 +52,7 @@ SIGNATURES = {
     'dvae_indep_fwd_f32': (I, [P, P, P, P, L, L, L, P]),
     'dvae_indep_bwd_f32': (I, [P, P, P, P, F, P, P, L, L, L, P]),
     'dvae_bn_finalize_f32': (I, [P, L, L, L, P, P, P, P, P, F, F, P, P, P, P, P]),
+    'dvae_bn_finalize_rep_f32': (I, [P, L, L, L, L, P, P, P, P, P, F, F, P, P, P, P, P]),
     'dvae_bn_eval_affine_f32': (I, [P, P, P, P, F, P, P, L, P]),
     'dvae_affine_act_f32': (I, [P, P, P, I, P, L, L, P]),
     'dvae_colsum_ws_floats': (L, [L, L]),

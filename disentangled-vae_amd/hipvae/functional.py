@@ -43,9 +43,9 @@ class BNState:
         self.rm, self.rv, self.nbt = running_mean, running_var, num_batches_tracked
 
 
-def _bn_affine(stats, nparts, M, gamma, beta, bn: BNState, training: bool):
+def _bn_affine(stats, nparts, M, gamma, beta, bn: BNState, training: bool, replicas: int = 1):
     if training:
-        return ops.bn_finalize(stats, nparts, M, gamma, beta, bn.rm, bn.rv, bn.nbt, BN_MOMENTUM, BN_EPS)
+        return ops.bn_finalize(stats, nparts, M, gamma, beta, bn.rm, bn.rv, bn.nbt, BN_MOMENTUM, BN_EPS, replicas)
     sc, sh = ops.bn_eval_affine(gamma, beta, bn.rm, bn.rv, BN_EPS)
     return sc, sh, None, None
 
@@ -248,10 +248,16 @@ def as_clips(frames: Tensor, B: int, T: int) -> Tensor:
 
 
 class DecoderCNN(torch.autograd.Function):
-    """CNNDecoder of the reference (models/decoders.py:11-70); returns frames [N, 1, 2^k*4, ...]."""
+    """CNNDecoder of the reference (models/decoders.py:11-70); returns frames [N, 1, 2^k*4, ...].
+
+    `replicas` > 1: the caller's batch is that many identical copies of each row of `feat` (BaselineVAE repeats one
+    latent per clip T times, models/baseline_vae.py:114-115) and hands over one copy.  The frames of the copies
+    are equal, the batch statistics of the repeated batch are those of one copy, and what backward needs of the
+    copies' gradients is their sum (which is what the caller's expand hands back), so the whole decoder runs on
+    N rows instead of N*replicas; only the running variance's unbiased correction uses the full count."""
 
     @staticmethod
-    def forward(ctx, feat: Tensor, training: bool, bns: List[BNState], fc_w: Tensor, fc_b: Tensor,
+    def forward(ctx, feat: Tensor, training: bool, bns: List[BNState], replicas: int, fc_w: Tensor, fc_b: Tensor,
                 final_w: Tensor, final_b: Tensor, *wgb: Tensor):
         _need_gpu(feat, 'DecoderCNN')
         L = len(bns)
@@ -275,7 +281,7 @@ class DecoderCNN(torch.autograd.Function):
             wpd = ops.pack_deconv_w(dec_w[l].detach())
             y, stats, nparts = ops.deconv4s2_fwd(cur, sc, sh, act, wpd, training)
             M = y.numel() // y.shape[-1]
-            aff = _bn_affine(stats, nparts, M, gammas[l].detach(), betas[l].detach(), bns[l], training)
+            aff = _bn_affine(stats, nparts, M, gammas[l].detach(), betas[l].detach(), bns[l], training, replicas)
             ys.append(y)
             affs.append(aff)
             cur, sc, sh, act = y, aff[0], aff[1], ops.ACT_LRELU
@@ -369,7 +375,7 @@ class DecoderCNN(torch.autograd.Function):
         d_fc_b = ops.permute3(d_bperm, (S, C0, 1), (1, 0, 2)).view(C0 * S)
         dfeat = ops.gemm_nn(dpre, w_perm)
         off.join()
-        return (dfeat, None, None, d_fc_w, d_fc_b, d_final_w, d_final_b, *d_dec, *d_gamma, *d_beta)
+        return (dfeat, None, None, None, d_fc_w, d_fc_b, d_final_w, d_final_b, *d_dec, *d_gamma, *d_beta)
 
 
 # =================================================================================================

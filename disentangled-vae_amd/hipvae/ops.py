@@ -264,15 +264,17 @@ def get_precision() -> str:
 
 
 def bn_finalize(partials: Tensor, nparts: int, M: int, gamma, beta, running_mean, running_var, nbt,
-                momentum: float, eps: float):
-    """-> (scale, shift, mean, invstd); updates the running buffers in place when given."""
+                momentum: float, eps: float, replicas: int = 1):
+    """-> (scale, shift, mean, invstd); updates the running buffers in place when given.  `replicas`: the layer's
+    batch is that many identical copies of the M rows behind the partial sums (only the unbiased correction of the
+    running variance sees it)."""
     _chk(partials, gamma, beta, running_mean, running_var)
     C = gamma.numel()
     out = torch.empty(4, C, dtype=torch.float32, device=gamma.device)
-    check(lib.dvae_bn_finalize_f32(_p(partials), nparts, M, C, _p(gamma), _p(beta), _p(running_mean),
-                                   _p(running_var), None if nbt is None else nbt.data_ptr(), float(momentum),
-                                   float(eps), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _stream()),
-          'bn_finalize')
+    check(lib.dvae_bn_finalize_rep_f32(_p(partials), nparts, M, int(replicas), C, _p(gamma), _p(beta),
+                                       _p(running_mean), _p(running_var), None if nbt is None else nbt.data_ptr(),
+                                       float(momentum), float(eps), _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]),
+                                       _stream()), 'bn_finalize')
     return out[0], out[1], out[2], out[3]
 
 

@@ -6,7 +6,6 @@ import torch
 import torch.nn as nn
 
 from hipvae.losses import baseline_loss as compute_loss  # noqa: F401  (reference name)
-from hipvae import functional as HF
 from hipvae.parallel import stage_boundary
 from .decoders import CNNDecoder
 from .encoders import CNNEncoder, VAEEncoder, reparameterize
@@ -38,9 +37,10 @@ class BaselineVAE(nn.Module):
     def decode(self, z: torch.Tensor, sequence_length: Optional[int] = None) -> torch.Tensor:
         B = z.size(0)
         T = sequence_length or self.sequence_length
-        zf = z.unsqueeze(1).expand(-1, T, -1).reshape(B * T, -1)
-        frames = self.cnn_decoder(zf)
-        return HF.as_clips(frames, B, T)
+        # the reference decodes z repeated T times (models/baseline_vae.py:114-121): T identical frames per clip.
+        # One copy is decoded and repeated; backward sums the copies' gradients through the expand.
+        frames = self.cnn_decoder(z, replicas=T)
+        return frames.unsqueeze(1).expand(B, T, *frames.shape[1:]).contiguous()
 
     def forward(self, video: torch.Tensor):
         z, mu, logvar = self.encode(video)

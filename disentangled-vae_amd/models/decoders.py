@@ -37,9 +37,11 @@ class CNNDecoder(nn.Module):
         self.final = nn.ConvTranspose2d(channels[-1], out_channels, kernel_size, stride, padding, bias=True)
         self.output_act = nn.Sigmoid()
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, replicas: int = 1) -> torch.Tensor:
+        """`replicas` (not in the reference): x stands for that many identical copies of each of its rows, see
+        hipvae.functional.DecoderCNN."""
         ws, gs, bs, handles = _stack_tensors(self.deconv)
-        return HF.DecoderCNN.apply(x, self.training, handles, self.fc[0].weight, self.fc[0].bias,
+        return HF.DecoderCNN.apply(x, self.training, handles, int(replicas), self.fc[0].weight, self.fc[0].bias,
                                    self.final.weight, self.final.bias, *ws, *gs, *bs)
 
 

@@ -160,6 +160,14 @@ int dvae_bn_finalize_f32(const float* partials, int64_t nparts, int64_t M, int64
                          const float* beta, float* running_mean, float* running_var,
                          int64_t* num_batches_tracked, float momentum, float eps, float* scale,
                          float* shift, float* mean, float* invstd, dvae_stream_t stream);
+/* The same when the layer's batch is `replicas` identical copies of the M rows behind the partial sums (the
+ * baseline model decodes one latent per clip and repeats the frame T times, models/baseline_vae.py:120-131: the
+ * copies are computed once).  Mean and biased variance do not change; the running variance takes its unbiased
+ * correction from the full count M*replicas, as nn.BatchNorm2d does on the repeated batch. */
+int dvae_bn_finalize_rep_f32(const float* partials, int64_t nparts, int64_t M, int64_t replicas, int64_t C,
+                             const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             int64_t* num_batches_tracked, float momentum, float eps, float* scale,
+                             float* shift, float* mean, float* invstd, dvae_stream_t stream);
 /* Eval mode: scale/shift from the running statistics. */
 int dvae_bn_eval_affine_f32(const float* gamma, const float* beta, const float* running_mean,
                             const float* running_var, float eps, float* scale, float* shift, int64_t C,
