@@ -56,9 +56,22 @@ class workspace_slot:
         return False
 
 
+# streams whose ops take their scratch from a slot of their own whenever they run there (forward under a stream
+# context, backward wherever autograd replays the forward's stream): raw stream handle -> slot name
+_STREAM_SLOT = {}
+
+
+def register_stream_slot(stream: 'torch.cuda.Stream', slot: str) -> None:
+    _STREAM_SLOT[stream.cuda_stream] = slot
+
+
 def workspace(nfloats: int, device, slot: Optional[str] = None) -> Tensor:
     """Grow-only scratch buffer per (device, slot); contents are only valid within one op."""
-    key = (torch.device(device).index, slot if slot is not None else _WS_SLOT[-1])
+    if slot is None:
+        slot = _WS_SLOT[-1]
+        if _STREAM_SLOT and slot == 'main':
+            slot = _STREAM_SLOT.get(torch.cuda.current_stream(device).cuda_stream, 'main')
+    key = (torch.device(device).index, slot)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
         if buf is not None:

@@ -8,6 +8,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+from hipvae import functional as HF
 from hipvae import ops
 from hipvae.losses import disentangled_loss as compute_loss  # noqa: F401  (reference name)
 from hipvae.parallel import stage_boundary
@@ -42,6 +43,14 @@ class DisentangledVAE(nn.Module):
     def encode(self, video: torch.Tensor):
         # one pass over the clip yields both the temporal mean and the frame differences
         mean, diff = ops.split_mean_diff(video.contiguous())
+        if HF.USE_SIDE_ENCODER and video.is_cuda:
+            with HF.side_branch(video) as br:
+                br.take(mean)
+                z_c, (mu_c, lv_c) = self.content_encoder(video, _mean=mean)      # content draw first
+                br.hand_over(z_c, mu_c, lv_c)
+            z_m, (mu_m, lv_m) = self.motion_encoder(video, _diff=diff)
+            br.join()
+            return z_c, z_m, (mu_c, lv_c), (mu_m, lv_m)
         z_c, (mu_c, lv_c) = self.content_encoder(video, _mean=mean)      # content draw first
         z_m, (mu_m, lv_m) = self.motion_encoder(video, _diff=diff)
         return z_c, z_m, (mu_c, lv_c), (mu_m, lv_m)
