@@ -33,6 +33,8 @@ class _Bucket:
         self.got = [False] * len(params)
         self.work = None
         self.event = None
+        self.streams = {}          # streams on which gradients of this bucket were produced this step
+
 
 
 class GradSync:
@@ -79,15 +81,26 @@ class GradSync:
         b, i = self._where[p]
         b.got[i] = True
         b.pending -= 1
+        # autograd runs a node's backward on the stream its forward ran on: parts of a model that ran on a second
+        # stream deliver their gradients there
+        if self.device.type == 'cuda':
+            cur = torch.cuda.current_stream(self.device)
+            b.streams[cur.cuda_stream] = cur
         if b.pending == 0:
             self._fill(b)
             self._launch(b)
 
-    @staticmethod
-    def _fill(b: _Bucket):
+    def _fill(self, b: _Bucket):
         """Move the finished gradients of a bucket into its flat buffer with one multi-tensor copy
         (one launch per bucket instead of one per parameter) and drop the originals: the bucket
-        slices become the gradients in finish()."""
+        slices become the gradients in finish().  The copy runs on the current stream, behind everything
+        queued so far on the other streams that produced gradients of this bucket."""
+        if b.streams:
+            cur = torch.cuda.current_stream(self.device)
+            for handle, other in b.streams.items():
+                if handle != cur.cuda_stream:
+                    cur.wait_stream(other)
+            b.streams = {}
         idx = [i for i, got in enumerate(b.got) if got and b.params[i].grad is not None
                and b.params[i].grad.data_ptr() != b.views[i].data_ptr()]
         if idx:
