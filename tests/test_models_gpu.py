@@ -177,6 +177,43 @@ def test_a_second_consumer_of_the_reconstruction_is_added_correctly_to_the_logit
         assert rel(one[n].cpu().numpy(), two[n].cpu().numpy()) < 2e-5, (n, rel(one[n].cpu().numpy(), two[n].cpu().numpy()))
 
 
+def test_content_encoder_runs_on_its_own_stream_with_its_own_scratch_forward_and_backward():
+    # every scratch request made while the second stream is current (forward under the stream context, backward
+    # wherever autograd replays it) must get the second stream's buffer, and both passes must make such requests
+    from hipvae import functional as HF, ops, rng
+    assert HF.USE_SIDE_ENCODER
+    g = load_step('disentangled')
+    m = build('disentangled', g).train()
+    video = torch.from_numpy(g['video']).cuda()
+    eps = [torch.from_numpy(g[f'eps{k}']) for k in range(2)]
+    seen = {'fwd': [], 'bwd': []}
+    phase = ['fwd']
+    plain = ops.workspace
+
+    def spy(nfloats, device, slot=None):
+        buf = plain(nfloats, device, slot)
+        side = HF._SIDE_STREAMS.get(torch.device(device).index)
+        on_side = side is not None and torch.cuda.current_stream(device).cuda_stream == side.cuda_stream
+        if slot is None:
+            mine = ops._WS.get((torch.device(device).index, 'side_branch'))
+            seen[phase[0]].append((on_side, mine is not None and buf.data_ptr() == mine.data_ptr()))
+        return buf
+    ops.workspace = spy
+    try:
+        with rng.inject_eps(eps):
+            out = m(video)
+        total = loss_of('disentangled', out, video, SETTINGS['tcfg']['disentangled'], SETTINGS['beta'])['total_loss']
+        phase[0] = 'bwd'
+        total.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.workspace = plain
+    for ph in ('fwd', 'bwd'):
+        assert any(on_side for on_side, _ in seen[ph]), ph
+        assert any(not on_side for on_side, _ in seen[ph]), ph
+        assert all(on_side == got_side_buffer for on_side, got_side_buffer in seen[ph]), ph
+
+
 FULL = {
     'disentangled': dict(content_dim=128, motion_dim=128, content_channels=[32, 64, 128, 256],
                          motion_channels=[16, 32], decoder_channels=[256, 128, 64, 32], content_feature_dim=512,
