@@ -318,11 +318,18 @@ def main():
             el = tt.item()
         return el, out
 
+    def make_infer_step():
+        model.eval()
+        if args.graph == 0:
+            return infer_step
+        from hipvae.graph import GraphedForward
+        gfwd = GraphedForward(model, ring[0])
+        return lambda i: gfwd(ring[i % len(ring)])
+
     if args.mode == 'train':
         step = make_train_step()
     else:
-        model.eval()
-        step = infer_step
+        step = make_infer_step()
     if args.host_batches:
         # PCIe-inclusive variant: the same step fed from pinned host memory
         host_ring = [v.cpu().pin_memory() for v in ring]
@@ -408,11 +415,11 @@ def main():
         result['roofline'] = {'whole_step': whole}
     if args.mode == 'train' and not args.no_extras and world == 1:
         # the same job's inference rate (eval-mode forward, no_grad) and its bf16-MFMA variant
-        model.eval()
-        el, _ = measure(infer_step, args.steps, min(args.warmup, 3))
+        el, _ = measure(make_infer_step(), args.steps, min(args.warmup, 3))
         result['inference'] = {'value': round(world * B * args.steps / el, 2), 'unit': 'clips/s',
                                'ms_per_step': round(el / args.steps * 1e3, 3),
-                               'workload': f'eval-mode forward (no_grad), batch {B}/GPU, {prec_label}'}
+                               'workload': f'eval-mode forward (no_grad), batch {B}/GPU, {prec_label}'
+                                           + (', hipGraph replay' if args.graph != 0 else '')}
         model.train()
         if args.precision == 'fp32':
             ops.set_precision('bf16')

@@ -550,3 +550,21 @@ def test_device_prefetcher_hands_over_every_batch_in_order():
     out = list(DevicePrefetcher(on_device, torch.device('cuda')))
     assert out[0][0] is on_device[0][0]
     assert list(DevicePrefetcher([], torch.device('cuda'))) == []
+
+def test_graphed_forward_replays_the_eval_forward():
+    # the captured no-grad forward returns what the eager one returns, for every batch it is given
+    import models
+    from hipvae.graph import GraphedForward
+    torch.manual_seed(3)
+    m = models.get_model('disentangled', in_channels=1, content_dim=16, motion_dim=16, content_channels=[8, 16, 32, 64],
+                         motion_channels=[8, 16], decoder_channels=[64, 32, 16, 8], content_feature_dim=64,
+                         motion_feature_dim=64, lstm_hidden=128, lstm_layers=1, bidirectional=True,
+                         sequence_length=6).cuda().eval()
+    clips = [torch.rand(3, 6, 1, 64, 64, device='cuda') for _ in range(3)]
+    g = GraphedForward(m, clips[0])
+    for v in clips[::-1]:
+        got = {k: t.clone() for k, t in g(v).items()}
+        with torch.no_grad():
+            want = m(v)
+        for k in want:
+            assert torch.equal(got[k], want[k]), k
