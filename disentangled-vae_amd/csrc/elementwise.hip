@@ -761,8 +761,10 @@ indep_stats_kernel(const float* __restrict__ z, float* __restrict__ mean, float*
 __global__ void __launch_bounds__(256)
 indep_corr_kernel(const float* __restrict__ zc, const float* __restrict__ zm, float* __restrict__ ws, int64_t B,
                   int64_t Dc, int64_t Dm) {
-  // one workgroup per content column i; threads over motion columns j
+  // one workgroup per content column i.  Thread (bs, jl): batch rows b = bs, bs+8, ... and motion columns
+  // j = jl, jl+32, ... (a row of zm is read as contiguous 128-byte pieces); the eight row slices meet in LDS.
   __shared__ double red[4];
+  __shared__ float partial[8][256 + 1];
   float* corr = ws;
   const float* mean_c = ws + Dc * Dm;
   const float* inv_c = mean_c + Dc;
@@ -771,12 +773,33 @@ indep_corr_kernel(const float* __restrict__ zc, const float* __restrict__ zm, fl
   float* part = const_cast<float*>(inv_m) + Dm;
   const int64_t i = blockIdx.x;
   const float mc = mean_c[i], ic = inv_c[i];
+  const int bs = threadIdx.x >> 5, jl = threadIdx.x & 31;
+  constexpr int JK = 8;                      // columns per thread: Dm <= 256
+  float mm[JK], im[JK], acc[JK];
+#pragma unroll
+  for (int k = 0; k < JK; ++k) {
+    const int64_t j = jl + 32 * k;
+    mm[k] = j < Dm ? mean_m[j] : 0.f;
+    im[k] = j < Dm ? inv_m[j] : 0.f;
+    acc[k] = 0.f;
+  }
+  for (int64_t b = bs; b < B; b += 8) {
+    const float xc = (zc[b * Dc + i] - mc) * ic;
+#pragma unroll
+    for (int k = 0; k < JK; ++k) {
+      const int64_t j = jl + 32 * k;
+      if (j < Dm) acc[k] += xc * ((zm[b * Dm + j] - mm[k]) * im[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < JK; ++k) partial[bs][jl + 32 * k] = acc[k];
+  __syncthreads();
   double sq = 0.0;
   for (int64_t j = threadIdx.x; j < Dm; j += 256) {
-    const float mm = mean_m[j], im = inv_m[j];
-    float acc = 0.f;
-    for (int64_t b = 0; b < B; ++b) acc += ((zc[b * Dc + i] - mc) * ic) * ((zm[b * Dm + j] - mm) * im);
-    const float c = acc / (float)B;
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a += partial[q][j];
+    const float c = a / (float)B;
     corr[i * Dm + j] = c;
     sq += (double)c * (double)c;
   }
@@ -801,21 +824,43 @@ indep_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Y, const
                  const float* __restrict__ mean_y, const float* __restrict__ inv_y,
                  const float* __restrict__ gscale, float coef, float* __restrict__ dX, int64_t B, int64_t Dx,
                  int64_t Dy) {
-  // one workgroup per column i of X
+  // one workgroup per column i of X.  Eight adjacent lanes share a batch row: each takes a contiguous eighth of
+  // the other side's columns (its correlation coefficients and column statistics stay in registers), so a row
+  // is read as one contiguous piece and the workgroup covers 32 rows per pass.
   extern __shared__ float gx_s[];  // B floats
   __shared__ double red[4];
   const int64_t i = blockIdx.x;
   const float g = coef * (gscale ? gscale[0] : 1.f);
   const float mx = mean_x[i], ix = inv_x[i];
   const float gfac = 2.f / (float)(Dx * Dy) / (float)B;
+  constexpr int JMAX = 32;                   // columns per lane: Dy <= 256
+  const int js = threadIdx.x & 7, rb = threadIdx.x >> 3;
+  const int per = (int)((Dy + 7) / 8), j0 = js * per;
+  float cj[JMAX], myj[JMAX];
+#pragma unroll
+  for (int u = 0; u < JMAX; ++u) {
+    const int j = j0 + u;
+    const bool ok = u < per && j < Dy;
+    cj[u] = ok ? corr[i * sx + j * sy] * inv_y[j] : 0.f;      // coefficient times 1/std of column j
+    myj[u] = ok ? mean_y[j] : 0.f;
+  }
   double s1 = 0.0, s2 = 0.0;
-  for (int64_t b = threadIdx.x; b < B; b += 256) {
+  for (int64_t b0 = 0; b0 < B; b0 += 32) {
+    const int64_t b = b0 + rb;
     float acc = 0.f;
-    for (int64_t j = 0; j < Dy; ++j) acc += corr[i * sx + j * sy] * ((Y[b * Dy + j] - mean_y[j]) * inv_y[j]);
-    const float gx = acc * gfac;  // dL/d xtilde_bi
-    gx_s[b] = gx;
-    s1 += (double)gx;
-    s2 += (double)gx * (double)(X[b * Dx + i] - mx);
+    if (b < B) {
+#pragma unroll
+      for (int u = 0; u < JMAX; ++u)
+        if (u < per && j0 + u < Dy) acc += cj[u] * (Y[b * Dy + j0 + u] - myj[u]);
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) acc += __shfl_xor(acc, o);
+    if (js == 0 && b < B) {
+      const float gx = acc * gfac;  // dL/d xtilde_bi
+      gx_s[b] = gx;
+      s1 += (double)gx;
+      s2 += (double)gx * (double)(X[b * Dx + i] - mx);
+    }
   }
   s1 = block_sum_256(s1, red);
   __shared__ double s1_s, s2_s;
@@ -838,6 +883,7 @@ extern "C" int64_t dvae_indep_ws_floats(int64_t Dc, int64_t Dm) { return Dc * Dm
 extern "C" int dvae_indep_fwd_f32(const float* zc, const float* zm, float* out, float* ws, int64_t B, int64_t Dc,
                                   int64_t Dm, dvae_stream_t stream) {
   DVAE_REQUIRE(B > 0 && Dc > 0 && Dm > 0, "indep_fwd: empty");
+  DVAE_REQUIRE(Dm <= 256, "indep_fwd: motion latent sizes above 256 are not supported (Dm=%ld)", (long)Dm);
   float* mean_c = ws + Dc * Dm;
   float* inv_c = mean_c + Dc;
   float* mean_m = inv_c + Dc;
@@ -855,6 +901,8 @@ extern "C" int dvae_indep_bwd_f32(const float* zc, const float* zm, const float*
                                   float* dzc, float* dzm, int64_t B, int64_t Dc, int64_t Dm, dvae_stream_t stream) {
   DVAE_REQUIRE(B > 0 && Dc > 0 && Dm > 0, "indep_bwd: empty");
   DVAE_REQUIRE(B * 4 <= 64 * 1024, "indep_bwd: batch %ld too large for the LDS staging buffer", (long)B);
+  DVAE_REQUIRE(Dc <= 256 && Dm <= 256, "indep_bwd: latent sizes above 256 are not supported (Dc=%ld Dm=%ld)", (long)Dc,
+               (long)Dm);
   const float* corr = ws;
   const float* mean_c = ws + Dc * Dm;
   const float* inv_c = mean_c + Dc;

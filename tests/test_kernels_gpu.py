@@ -113,7 +113,7 @@ def test_reparam_and_kl(ops):
         assert rel_err(dmu, gm) < 2e-6 and rel_err(dlv, gl) < 2e-6
 
 
-@pytest.mark.parametrize('B,Dc,Dm', [(4, 16, 16), (32, 128, 128), (9, 8, 20)])
+@pytest.mark.parametrize('B,Dc,Dm', [(4, 16, 16), (32, 128, 128), (9, 8, 20), (256, 128, 128), (70, 250, 37), (3, 5, 256)])
 def test_independence(ops, B, Dc, Dm):
     zc, zm = rnd(B, Dc, seed=7), rnd(B, Dm, seed=8) + 0.3 * rnd(B, 1, seed=9)
     a, b = zc.clone().requires_grad_(True), zm.clone().requires_grad_(True)
