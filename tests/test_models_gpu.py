@@ -177,6 +177,18 @@ def test_a_second_consumer_of_the_reconstruction_is_added_correctly_to_the_logit
         assert rel(one[n].cpu().numpy(), two[n].cpu().numpy()) < 2e-5, (n, rel(one[n].cpu().numpy(), two[n].cpu().numpy()))
 
 
+def test_second_stream_changes_no_bit_of_the_gradients():
+    from hipvae import functional as HF
+    two = _grads_of_step('disentangled')
+    old, HF.USE_SIDE_ENCODER = HF.USE_SIDE_ENCODER, False
+    try:
+        one = _grads_of_step('disentangled')
+    finally:
+        HF.USE_SIDE_ENCODER = old
+    for n in one:
+        assert torch.equal(one[n], two[n]), n
+
+
 def test_content_encoder_runs_on_its_own_stream_with_its_own_scratch_forward_and_backward():
     # every scratch request made while the second stream is current (forward under the stream context, backward
     # wherever autograd replays it) must get the second stream's buffer, and both passes must make such requests
