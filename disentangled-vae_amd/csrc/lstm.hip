@@ -1067,6 +1067,34 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_dec_fwd_kernel(LstmDecArg
   __syncthreads();
 
   const int ncells = g.T * DEC_L;
+  // The recurrent half of a cell's product does not wait for the cell before it: cell s needs the output of cell
+  // s-1 as its input x, and that same tensor is the previous hidden state of cell s+1 (layer 1 at step t follows
+  // layer 0 at step t, whose x was h_{1,t-1}; layer 0 at step t+1 follows layer 1 at step t, whose x was h_{0,t}).
+  // So a cell multiplies x with its W_ih on the critical path and, behind its hand-off, the same x with the NEXT
+  // cell's W_hh; only the two cells of step 0 take their previous state from h0.
+  auto mul = [&](const f32x4 (&a)[NQ / 4], const float (&w)[NQ], f32x16 acc) {
+#pragma unroll
+    for (int q = 0; q < NQ / 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], w[4 * q + e], acc, 0, 0, 0);
+    return acc;
+  };
+  auto h0_rows = [&](int l, f32x4 (&a)[NQ / 4]) {
+#pragma unroll
+    for (int q = 0; q < NQ / 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(g.h0 + arc * g.ld_h0 + l * H + kbase + 4 * q);
+      a[q] = arow_ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  f32x16 zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+  f32x16 rec;                                   // h_prev W_hh^T of the cell about to run
+  {
+    f32x4 ah[NQ / 4];
+    h0_rows(0, ah);
+    rec = mul(ah, wh[0], zero16);
+  }
 #pragma unroll 1
   for (int t = 0; t < g.T; ++t) {
 #pragma unroll
@@ -1075,8 +1103,8 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_dec_fwd_kernel(LstmDecArg
       if (s > 0) {
         if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)s, &s_abort)) return;
       }
-      // the two operands: x (the cell below, or the top layer's previous output) and this layer's previous h
-      f32x4 ax[NQ / 4], ah[NQ / 4];
+      // x: the cell below, or the top layer's previous output (the learned first input at the very start)
+      f32x4 ax[NQ / 4];
       if (l == 0 && t == 0) {
 #pragma unroll
         for (int q = 0; q < NQ / 4; ++q) ax[q] = *reinterpret_cast<const f32x4*>(g.init + kbase + 4 * q);
@@ -1087,39 +1115,13 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_dec_fwd_kernel(LstmDecArg
           const int u = kbase + 4 * q;
           ax[q] = load_x4_sc1(src + ((int64_t)(u >> 3) * 32 + l31) * 8 + (u & 7));
         }
+        // the write-through-coherent loads above are invisible to the compiler's wait counters
+        if constexpr (NQ / 4 == 2)
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(ax[0]), "+v"(ax[1]) : : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(ax[0]), "+v"(ax[1]), "+v"(ax[2]), "+v"(ax[3]) : : "memory");
       }
-      if (t == 0) {
-#pragma unroll
-        for (int q = 0; q < NQ / 4; ++q) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(g.h0 + arc * g.ld_h0 + l * H + kbase + 4 * q);
-          ah[q] = arow_ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-      } else {
-        const float* src = xch + (int64_t)(l * 2 + ((t - 1) & 1)) * H * 32;
-#pragma unroll
-        for (int q = 0; q < NQ / 4; ++q) {
-          const int u = kbase + 4 * q;
-          ah[q] = load_x4_sc1(src + ((int64_t)(u >> 3) * 32 + l31) * 8 + (u & 7));
-        }
-      }
-      // the write-through-coherent loads above are invisible to the compiler's wait counters
-      if constexpr (NQ / 4 == 2)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ax[0]), "+v"(ax[1]), "+v"(ah[0]), "+v"(ah[1]) : : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(ax[0]), "+v"(ax[1]), "+v"(ax[2]), "+v"(ax[3]), "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3])
-                     : : "memory");
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int q = 0; q < NQ / 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[q][e], wx[l][4 * q + e], acc, 0, 0, 0);
-#pragma unroll
-      for (int q = 0; q < NQ / 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ah[q][e], wh[l][4 * q + e], acc, 0, 0, 0);
+      const f32x16 acc = mul(ax, wx[l], rec);
       ks_spill(red, acc, wave, lane);
       __syncthreads();
       float ig_o = 0.f, fg_o = 0.f, gg_o = 0.f, og_o = 0.f, hn_o = 0.f;
@@ -1156,6 +1158,16 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_dec_fwd_kernel(LstmDecArg
         go[3 * H + j] = og_o;
         g.cs[row * H + j] = cstate[l];
         g.hs[row * H + j] = hn_o;
+      }
+      // behind the hand-off: the recurrent half of the next cell (layer 1 - l)
+      if (s + 1 < ncells) {
+        if (s == 0) {
+          f32x4 ah[NQ / 4];
+          h0_rows(1, ah);
+          rec = mul(ah, wh[1], zero16);
+        } else {
+          rec = mul(ax, wh[DEC_L - 1 - l], zero16);
+        }
       }
     }
   }
@@ -1357,13 +1369,17 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_dec_bwd_kernel(LstmDecBwd
         As[bl * SEQ_A_LD + 3 * 8 + jj] = dg3;
       }
       __syncthreads();
+      // Input path: to the cell that fed this one its x -- the NEXT cell of the chain, which waits for it.
+      // Recurrent path: to this layer's previous step, two cells on; it is written behind this cell's arrival and
+      // is covered by the next cell's (a wave drains all its stores before its workgroup signals).  The chain's
+      // last cell has no next arrival and writes both in front of its own.
+      const bool last = sigma + 1 == T * DEC_L;
+      f32x4 av[4];
       if (has_tile) {
-        f32x4 av[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const f32x4*>(&As[l31 * SEQ_A_LD + 16 * hh + 4 * q]);
-        // input path: to the cell that fed this one its x; recurrent path: to this layer's previous step
         product(av, wx[l], l > 0 ? buf_of(0, l - 1, t) : buf_of(0, DEC_L - 1, t - 1));
-        product(av, wh[l], buf_of(1, l, t - 1));
+        if (last) product(av, wh[l], buf_of(1, l, t - 1));
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -1372,6 +1388,7 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_dec_bwd_kernel(LstmDecBwd
         float* dg = g.dgates + row * 4 * H + j;
         dg[0] = dg0; dg[H] = dg1; dg[2 * H] = dg2; dg[3 * H] = dg3;
       }
+      if (has_tile && !last) product(av, wh[l], buf_of(1, l, t - 1));
     }
   }
   // what left the chain at its end: destination step -1 (odd parity)

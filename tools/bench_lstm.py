@@ -89,6 +89,26 @@ def main():
             us = replay_time(lambda: ops.lstm_seq_bwd(two, T, Bs, H))
             print(f'   two chains (both directions) in one launch, B={Bs:3d}: {us / T:6.2f} us per step', flush=True)
 
+    # the stacked (two-layer) autoregressive decoder: one launch each way, 2 T cells in a chain
+    Td = 20
+    for Bs in (32, 256):
+        if not ops.lstm_dec2_supported(Td, Bs, H):
+            continue
+        wts = [torch.randn(4 * H, H, device=dev) * 0.05, torch.randn(4 * H, H, device=dev) * 0.05,
+               torch.zeros(4 * H, device=dev), torch.zeros(4 * H, device=dev)] * 2
+        h0, c0 = torch.randn(Bs, 2 * H, device=dev) * 0.1, torch.randn(Bs, 2 * H, device=dev) * 0.1
+        init = torch.randn(H, device=dev) * 0.1
+        gates2 = torch.empty(2, Td, Bs, 4 * H, device=dev)
+        hs2, cs2 = torch.empty(2, Td, Bs, H, device=dev), torch.empty(2, Td, Bs, H, device=dev)
+        us = replay_time(lambda: ops.lstm_dec2_fwd(wts, h0, c0, init, gates2, hs2, cs2))
+        print(f'stacked decoder forward,  one launch, B={Bs:3d}: {us / (2 * Td):6.2f} us per cell', flush=True)
+        ext = torch.randn(Bs, Td, H, device=dev) * 0.1
+        dg2 = torch.empty(2, Td, Bs, 4 * H, device=dev)
+        dh0, dc0 = torch.empty(Bs, 2 * H, device=dev), torch.empty(Bs, 2 * H, device=dev)
+        dx0 = torch.empty(Bs, H, device=dev)
+        us = replay_time(lambda: ops.lstm_dec2_bwd(wts, gates2, cs2, c0, ext, dg2, dh0, dc0, dx0))
+        print(f'stacked decoder backward, one launch, B={Bs:3d}: {us / (2 * Td):6.2f} us per cell', flush=True)
+
     # for scale: the same number of empty-ish dependent launches (a 1-block fill kernel)
     z = torch.zeros(64, device=dev)
 
