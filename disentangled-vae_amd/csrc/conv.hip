@@ -103,6 +103,13 @@ struct ConvArgs {
   const float* in_b;
   float* dx_out;
   int mt0;          // tiled kernels: first M tile of this launch (a layer may be split over two launches)
+  // tiled kernels, K split over gridDim.z (few M tiles: every workgroup takes kt_per K tiles and writes its partial
+  // output, in output layout, to slab + blockIdx.z * slab_stride; conv_slab_reduce_kernel sums them); nullptr: no split
+  float* slab;
+  int64_t slab_stride;
+  int kt_per;
+  float* ws;        // scratch the caller brought (may be nullptr) and its size
+  int64_t ws_floats;
 };
 
 // A operand of the forward implicit GEMMs.  MODE 0: conv (16 taps, input pixel 2*o-1+k);
@@ -112,7 +119,8 @@ struct ConvArgs {
 // and one bit per filter tap saying whether that tap falls inside the frame.  A K tile then costs a
 // bit test and one address add per 16-byte load.  issue() only starts loads (masked-out chunks read
 // x[0..3], which is always there, and are zeroed in finish()); the BatchNorm scale/shift of the K
-// tile's channels ride along as two more loads in flight.  K tiles must be visited in order from 0.
+// tile's channels ride along as two more loads in flight.  K tiles must be visited in order, from the one
+// given to seek() (0 by default).
 template <int V4, int MODE, bool C1>
 struct ConvALoader {
   const ConvArgs& g;
@@ -121,9 +129,11 @@ struct ConvALoader {
   unsigned tapmask[V4];
   int h0[V4], w0[V4];     // single-channel path only
   int tap, ci0;           // position of the current K tile (uniform path)
+  int kt0;                // first K tile of the walk
   unsigned mask;
   float4 sc, sh;
-  __device__ __forceinline__ ConvALoader(const ConvArgs& g_, int ph_, int pw_) : g(g_), ph(ph_), pw(pw_) {}
+  __device__ __forceinline__ ConvALoader(const ConvArgs& g_, int ph_, int pw_) : g(g_), ph(ph_), pw(pw_), kt0(0) {}
+  __device__ __forceinline__ void seek(int kt_first) { kt0 = kt_first; }
   __device__ __forceinline__ void set_tile(int64_t m0) {
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
@@ -185,9 +195,10 @@ struct ConvALoader {
     int tp, ci;
     bool kok;
     if (g.cin32) {
-      if (kt == 0) {
-        tap = 0;
-        ci0 = 0;
+      if (kt == kt0) {
+        const int k0 = kt * 32;
+        tap = g.lc >= 0 ? k0 >> g.lc : k0 / g.Cin;
+        ci0 = k0 - tap * g.Cin;
       } else {
         ci0 += 32;
         if (ci0 >= g.Cin) {
@@ -275,13 +286,18 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
   float s1[T::TN], s2[T::TN];
 #pragma unroll
   for (int j = 0; j < T::TN; ++j) s1[j] = s2[j] = 0.f;
+  const bool split = g.slab != nullptr;
+  const int kt_begin = split ? (int)blockIdx.z * g.kt_per : 0;
+  const int kt_end = split ? (kt_begin + g.kt_per < ktiles ? kt_begin + g.kt_per : ktiles) : ktiles;
+  float* const yout = split ? g.slab + (int64_t)blockIdx.z * g.slab_stride : g.y;
+  la.seek(kt_begin);
 
   for (int mt = g.mt0 + bx; mt < g.mtiles; mt += gx) {
     const int64_t m0 = (int64_t)mt * T::BM;
     la.set_tile(m0);
     f32x16 acc[T::TM][T::TN];
     zero_acc<T>(acc);
-    gemm_mainloop<T, BF>(la, lb, 0, ktiles, smem, acc);
+    gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
 
     // store raw output
     for_each_acc<T>(acc, [&](int r, int c, float v) {
@@ -296,10 +312,10 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
           const int64_t img = m >> (g.lw + g.lh);
           orow = (img * (2 * g.H) + (2 * a + ph)) * (2 * g.W) + (2 * b + pw);
         }
-        g.y[orow * g.Cout + n] = v;
+        yout[orow * g.Cout + n] = v;
       }
     });
-    if (g.stats && !BNS) {
+    if (g.stats && !BNS && !split) {
 #pragma unroll
       for (int i = 0; i < T::TM; ++i)
 #pragma unroll
@@ -348,7 +364,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
     }
   }
 
-  if (g.stats) {
+  if (g.stats && !split) {
     // lanes l and l+32 hold the same column; waves with equal wn hold the same columns
     float* red = smem;  // [4 waves][TN*32][2]
     __syncthreads();
@@ -1167,6 +1183,58 @@ static int64_t conv_parts_written(int64_t M, int phases) {
   return mt * phases;
 }
 
+// K split of the tiled kernels: how many ways (0: no split).  For layers whose 128-wide tiles fill between a quarter
+// and half of the chip's 512 workgroup slots and whose K loop is long enough to share out.  (Fewer tiles than that
+// are better served by narrower tiles, which already give every compute unit a workgroup: measured 68 vs 76 us and
+// 36 vs 51 us with the split at 64 and 8 tiles; at 160 tiles the split takes 129 us against 170.)
+static int conv_split_ways(int64_t M, int phases, int64_t Cout, int64_t K) {
+  if (Cout < 128 || Cout % 4 != 0 || 256 % (Cout / 4) != 0) return 0;
+  const int64_t tiles128 = ceil_div64(M, 128) * phases * ceil_div64(Cout, 128);
+  const int64_t ktiles = ceil_div64(K, 32);
+  if (tiles128 <= 128 || tiles128 > 256 || ktiles < 32) return 0;
+  int64_t S = 512 / tiles128;
+  if (S > 4) S = 4;
+  if (S > ktiles / 16) S = ktiles / 16;     // a share shorter than 16 K tiles costs more in prologue, epilogue and
+                                            // summing than the fuller chip returns (measured: 8 per share, +10 %)
+  while (S >= 2 && (S - 1) * ceil_div64(ktiles, S) >= ktiles) --S;    // no empty share
+  return S >= 2 ? (int)S : 0;
+}
+
+// Sum of the K-split partial outputs (fixed order), written to y; with stats != nullptr also the forward
+// BatchNorm partial sums (sum, sum of squares per channel) of the rows a workgroup handles, one partial row per
+// workgroup.  Thread = four channels of every (256 / (Cout/4))-th row of the workgroup's run of rows.
+__global__ void __launch_bounds__(256)
+conv_slab_reduce_kernel(const float4* __restrict__ slab, int S, int64_t n4, int C4, float4* __restrict__ y,
+                        float* __restrict__ stats, int64_t rows, int64_t rows_per_part) {
+  __shared__ float red[2][256][4];
+  const int c4 = threadIdx.x % C4, rsub = threadIdx.x / C4, RG = 256 / C4;
+  const int64_t r0 = blockIdx.x * rows_per_part;
+  const int64_t r1 = r0 + rows_per_part < rows ? r0 + rows_per_part : rows;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  for (int64_t r = r0 + rsub; r < r1; r += RG) {
+    const int64_t idx = r * C4 + c4;
+    float4 v = slab[idx];
+    for (int z = 1; z < S; ++z) {
+      const float4 w = slab[(int64_t)z * n4 + idx];
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    y[idx] = v;
+    s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+    s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+  }
+  if (stats == nullptr) return;
+  red[0][threadIdx.x][0] = s1.x; red[0][threadIdx.x][1] = s1.y; red[0][threadIdx.x][2] = s1.z; red[0][threadIdx.x][3] = s1.w;
+  red[1][threadIdx.x][0] = s2.x; red[1][threadIdx.x][1] = s2.y; red[1][threadIdx.x][2] = s2.z; red[1][threadIdx.x][3] = s2.w;
+  __syncthreads();
+  const int Cout = 4 * C4;
+  for (int i = threadIdx.x; i < 2 * Cout; i += 256) {
+    const int which = i / Cout, c = i % Cout;
+    float a = 0.f;
+    for (int q = 0; q < RG; ++q) a += red[which][q * C4 + (c >> 2)][c & 3];
+    stats[((int64_t)blockIdx.x * 2 + which) * Cout + c] = a;
+  }
+}
+
 template <int MODE>
 static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t stream) {
   const bool c1 = g.Cin == 1;
@@ -1182,7 +1250,7 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
       g.mtiles = mt_end;                                                                             \
     }                                                                                                \
     int gx = g.mtiles - g.mt0 < CONV_MAX_PARTS ? g.mtiles - g.mt0 : CONV_MAX_PARTS;                  \
-    dim3 grid(gx * phases, (unsigned)ceil_div64(g.Cout, TILE::BN), 1);                               \
+    dim3 grid(gx * phases, (unsigned)ceil_div64(g.Cout, TILE::BN), (unsigned)ksplit);                \
     {                                                                                                \
       int64_t rows_ = (int64_t)g.mtiles * TILE::BM;                                                  \
       rows_ = (rows_ < g.M ? rows_ : g.M) - (int64_t)g.mt0 * TILE::BM;                               \
@@ -1200,6 +1268,7 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
       DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, false, false>), grid, dim3(256), 0, stream, g); \
   }
   int mt_begin = 0, mt_end = -1;       // M-tile range of the next LAUNCH (-1: the whole layer)
+  int ksplit = 1;                      // gridDim.z of the next LAUNCH
   typedef Tile<128, 128, 2, 2, true, true> T128;
   typedef Tile<128, 64, 4, 1, true, true> T64;
   typedef Tile<128, 32, 4, 1, true, true> T32;
@@ -1316,6 +1385,22 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   } else if (c1) {
     if (g.Cout > 32) LAUNCH(T64, true) else LAUNCH(T32, true)
   } else {
+    const int ways = (g.ws != nullptr && !bns) ? conv_split_ways(g.M, phases, g.Cout, g.K) : 0;
+    const int64_t out_floats = g.M * phases * g.Cout;
+    if (ways >= 2 && (int64_t)ways * out_floats <= g.ws_floats && aligned16(g.ws) && aligned16(g.y)) {
+      float* const stats_out = g.stats;
+      g.slab = g.ws;
+      g.slab_stride = out_floats;
+      g.kt_per = (int)ceil_div64(ceil_div64(g.K, 32), ways);
+      ksplit = ways;
+      LAUNCH(T128, false)
+      DVAE_LAUNCH_CHECK(name);
+      const int64_t parts = conv_parts_written(g.M, phases), rows = g.M * phases;
+      DVAE_LAUNCH(conv_slab_reduce_kernel, dim3((unsigned)parts), dim3(256), 0, stream, (const float4*)g.ws, ways,
+                  out_floats / 4, g.Cout / 4, (float4*)g.y, stats_out, rows, ceil_div64(rows, parts));
+      DVAE_LAUNCH_CHECK(name);
+      return 0;
+    }
     // the widest tile that still gives every compute unit a workgroup (all tiles are 128 rows high)
     const int64_t row_tiles = ceil_div64(g.M, 128) * phases;
     int bn = g.Cout > 64 ? 128 : (g.Cout > 32 ? 64 : 32);
@@ -1370,7 +1455,8 @@ struct BnBwdInput {  // see ConvArgs::in_y
 static int conv4s2_fwd_impl(const char* name, const float* x, const float* in_scale, const float* in_shift, int in_act,
                             const float* wp, float* y, float* stat_partials, int64_t N, int64_t H, int64_t W,
                             int64_t Cin, int64_t Cout, const BnBwdStat& bn, hipStream_t stream,
-                            const BnBwdInput& bi = BnBwdInput{nullptr, nullptr, nullptr, nullptr}) {
+                            const BnBwdInput& bi = BnBwdInput{nullptr, nullptr, nullptr, nullptr},
+                            float* ws = nullptr, int64_t ws_floats = 0) {
   DVAE_REQUIRE(N > 0 && Cout > 0, "%s: empty", name);
   DVAE_REQUIRE(is_pow2(H) && is_pow2(W) && H >= 2 && W >= 2, "%s: H and W must be powers of two >= 2 (H=%ld W=%ld)", name,
                (long)H, (long)W);
@@ -1390,6 +1476,7 @@ static int conv4s2_fwd_impl(const char* name, const float* x, const float* in_sc
   g.cin32 = Cin % 32 == 0;
   g.bn_y = bn.y; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_invstd = bn.invstd;
   g.in_y = bi.y; g.in_a = bi.a; g.in_b = bi.b; g.dx_out = bi.dx_out;
+  g.slab = nullptr; g.slab_stride = 0; g.kt_per = 0; g.ws = ws; g.ws_floats = ws_floats;
   DVAE_REQUIRE(bi.y == nullptr || (in_scale && in_shift && bi.a && bi.b && bi.dx_out && aligned16(bi.y) &&
                                    aligned16(bi.a) && aligned16(bi.b) && aligned16(bi.dx_out)),
                "%s: a BatchNorm-backward input needs y, scale, shift, A, B and dx_out, 16-byte aligned", name);
@@ -1399,7 +1486,8 @@ static int conv4s2_fwd_impl(const char* name, const float* x, const float* in_sc
 static int deconv4s2_fwd_impl(const char* name, const float* x, const float* in_scale, const float* in_shift,
                               int in_act, const float* wp, float* y, float* stat_partials, int64_t N, int64_t H,
                               int64_t W, int64_t Cin, int64_t Cout, const BnBwdStat& bn, hipStream_t stream,
-                              const BnBwdInput& bi = BnBwdInput{nullptr, nullptr, nullptr, nullptr}) {
+                              const BnBwdInput& bi = BnBwdInput{nullptr, nullptr, nullptr, nullptr},
+                              float* ws = nullptr, int64_t ws_floats = 0) {
   DVAE_REQUIRE(N > 0 && Cout > 0, "%s: empty", name);
   DVAE_REQUIRE(is_pow2(H) && is_pow2(W), "%s: H and W must be powers of two (H=%ld W=%ld)", name, (long)H, (long)W);
   DVAE_REQUIRE(Cin % 4 == 0, "%s: Cin must be a multiple of 4 (Cin=%ld)", name, (long)Cin);
@@ -1415,6 +1503,7 @@ static int deconv4s2_fwd_impl(const char* name, const float* x, const float* in_
   g.cin32 = Cin % 32 == 0;
   g.bn_y = bn.y; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_invstd = bn.invstd;
   g.in_y = bi.y; g.in_a = bi.a; g.in_b = bi.b; g.dx_out = bi.dx_out;
+  g.slab = nullptr; g.slab_stride = 0; g.kt_per = 0; g.ws = ws; g.ws_floats = ws_floats;
   DVAE_REQUIRE(bi.y == nullptr || (in_scale && in_shift && bi.a && bi.b && bi.dx_out && aligned16(bi.y) &&
                                    aligned16(bi.a) && aligned16(bi.b) && aligned16(bi.dx_out)),
                "%s: a BatchNorm-backward input needs y, scale, shift, A, B and dx_out, 16-byte aligned", name);
@@ -1433,6 +1522,32 @@ extern "C" int dvae_deconv4s2_fwd_f32(const float* x, const float* in_scale, con
                                       int64_t W, int64_t Cin, int64_t Cout, dvae_stream_t stream) {
   return deconv4s2_fwd_impl("deconv4s2_fwd", x, in_scale, in_shift, in_act, wp, y, stat_partials, N, H, W, Cin, Cout,
                             BnBwdStat{nullptr, nullptr, nullptr, nullptr, nullptr}, ST(stream));
+}
+
+extern "C" int64_t dvae_conv_fwd_ws_floats(int transposed, int64_t N, int64_t H, int64_t W, int64_t Cin,
+                                           int64_t Cout) {
+  const int64_t M = transposed ? N * H * W : N * (H / 2) * (W / 2);
+  const int phases = transposed ? 4 : 1;
+  const int ways = Cin == 1 ? 0 : conv_split_ways(M, phases, Cout, transposed ? 4 * Cin : 16 * Cin);
+  return (int64_t)ways * M * phases * Cout;
+}
+
+extern "C" int dvae_conv4s2_fwd_ws_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
+                                       const float* wp, float* y, float* stat_partials, int64_t N, int64_t H,
+                                       int64_t W, int64_t Cin, int64_t Cout, float* ws, int64_t ws_floats,
+                                       dvae_stream_t stream) {
+  return conv4s2_fwd_impl("conv4s2_fwd", x, in_scale, in_shift, in_act, wp, y, stat_partials, N, H, W, Cin, Cout,
+                          BnBwdStat{nullptr, nullptr, nullptr, nullptr, nullptr}, ST(stream),
+                          BnBwdInput{nullptr, nullptr, nullptr, nullptr}, ws, ws_floats);
+}
+
+extern "C" int dvae_deconv4s2_fwd_ws_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
+                                         const float* wp, float* y, float* stat_partials, int64_t N, int64_t H,
+                                         int64_t W, int64_t Cin, int64_t Cout, float* ws, int64_t ws_floats,
+                                         dvae_stream_t stream) {
+  return deconv4s2_fwd_impl("deconv4s2_fwd", x, in_scale, in_shift, in_act, wp, y, stat_partials, N, H, W, Cin, Cout,
+                            BnBwdStat{nullptr, nullptr, nullptr, nullptr, nullptr}, ST(stream),
+                            BnBwdInput{nullptr, nullptr, nullptr, nullptr}, ws, ws_floats);
 }
 
 extern "C" int dvae_conv4s2_dgrad_bnstat_f32(const float* x, const float* wp, float* y, float* stat_partials,

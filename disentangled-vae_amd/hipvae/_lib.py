@@ -71,6 +71,9 @@ SIGNATURES = {
     'dvae_conv_stat_parts_written': (L, [L, I]),
     'dvae_conv4s2_fwd_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P]),
     'dvae_deconv4s2_fwd_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P]),
+    'dvae_conv_fwd_ws_floats': (L, [I, L, L, L, L, L]),
+    'dvae_conv4s2_fwd_ws_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P, L, P]),
+    'dvae_deconv4s2_fwd_ws_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P, L, P]),
     'dvae_conv4s2_dgrad_bnstat_f32': (I, [P, P, P, P, L, L, L, L, L, P, P, P, P, P, P]),
     'dvae_deconv4s2_dgrad_bnstat_f32': (I, [P, P, P, P, L, L, L, L, L, P, P, P, P, P, P]),
     'dvae_bn_bwd_from_partials_f32': (I, [P, P, P, P, P, P, P, L, P, P, L, L, P]),

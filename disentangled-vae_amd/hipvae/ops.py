@@ -459,8 +459,10 @@ def conv4s2_fwd(x: Tensor, scale, shift, act: int, wp: Tensor, want_stats: bool)
     y = torch.empty(N, H // 2, W // 2, Cout, dtype=torch.float32, device=x.device)
     nparts = lib.dvae_conv_stat_parts_written(N * (H // 2) * (W // 2), 1)
     stats = torch.empty(nparts, 2, Cout, dtype=torch.float32, device=x.device) if want_stats else None
-    check(lib.dvae_conv4s2_fwd_f32(_p(x), _p(scale), _p(shift), act, _p(wp), _p(y), _p(stats), N, H, W, Cin, Cout,
-                                   _stream()), 'conv4s2_fwd')
+    need = lib.dvae_conv_fwd_ws_floats(0, N, H, W, Cin, Cout)
+    ws = workspace(need, x.device) if need else None
+    check(lib.dvae_conv4s2_fwd_ws_f32(_p(x), _p(scale), _p(shift), act, _p(wp), _p(y), _p(stats), N, H, W, Cin, Cout,
+                                      _p(ws), need, _stream()), 'conv4s2_fwd')
     return y, stats, nparts
 
 
@@ -472,8 +474,10 @@ def deconv4s2_fwd(x: Tensor, scale, shift, act: int, wp: Tensor, want_stats: boo
     y = torch.empty(N, 2 * H, 2 * W, Cout, dtype=torch.float32, device=x.device)
     nparts = lib.dvae_conv_stat_parts_written(N * H * W, 4)
     stats = torch.empty(nparts, 2, Cout, dtype=torch.float32, device=x.device) if want_stats else None
-    check(lib.dvae_deconv4s2_fwd_f32(_p(x), _p(scale), _p(shift), act, _p(wp), _p(y), _p(stats), N, H, W, Cin,
-                                     Cout, _stream()), 'deconv4s2_fwd')
+    need = lib.dvae_conv_fwd_ws_floats(1, N, H, W, Cin, Cout)
+    ws = workspace(need, x.device) if need else None
+    check(lib.dvae_deconv4s2_fwd_ws_f32(_p(x), _p(scale), _p(shift), act, _p(wp), _p(y), _p(stats), N, H, W, Cin,
+                                        Cout, _p(ws), need, _stream()), 'deconv4s2_fwd')
     return y, stats, nparts
 
 

@@ -256,6 +256,18 @@ int dvae_conv4s2_fwd_f32(const float* x, const float* in_scale, const float* in_
 int dvae_deconv4s2_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
                            const float* wp, float* y, float* stat_partials, int64_t N, int64_t H,
                            int64_t W, int64_t Cin, int64_t Cout, dvae_stream_t stream);
+/* The same two with scratch memory from the caller: layers with few row tiles (small batches, the late encoder
+ * layers) then share their K loop out over several workgroups per tile, which write partial outputs to the scratch
+ * and are summed in a fixed order by a second launch (which also takes the BatchNorm partial sums).  Results are
+ * those of the plain entry points up to the order of fp32 additions.  ws: dvae_conv_fwd_ws_floats(...) floats,
+ * 16-byte aligned; a smaller (or NULL) scratch turns the split off. */
+int64_t dvae_conv_fwd_ws_floats(int transposed, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout);
+int dvae_conv4s2_fwd_ws_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
+                            const float* wp, float* y, float* stat_partials, int64_t N, int64_t H, int64_t W,
+                            int64_t Cin, int64_t Cout, float* ws, int64_t ws_floats, dvae_stream_t stream);
+int dvae_deconv4s2_fwd_ws_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
+                              const float* wp, float* y, float* stat_partials, int64_t N, int64_t H, int64_t W,
+                              int64_t Cin, int64_t Cout, float* ws, int64_t ws_floats, dvae_stream_t stream);
 /* The two kernels above used as data gradients inside a conv -> BatchNorm -> LeakyReLU stack (autograd of
  * models/encoders.py:32-36 and models/decoders.py:40-45): x is dL/d(raw output of the next layer), y
  * receives du = dL/d(activation of this layer), unchanged; in the same pass the kernel also reduces what

@@ -224,6 +224,10 @@ CONV_CASES = [  # N, H, Cin, Cout
     # (32,64) and (16,32) on frames at least 32 wide take the row-ring kernel: one and two groups of
     # sixteen output pixels per row, more workgroups than share out the rows (N=300)
     (4, 32, 32, 64), (3, 64, 16, 32), (2, 64, 32, 64), (300, 32, 32, 64), (37, 32, 16, 32),
+    # 128-wide tiles on a quarter to half of the chip's workgroup slots: the K loop is shared out over several
+    # workgroups per tile and the partial outputs are summed by a second launch (three uneven shares at the
+    # batch-32 shape of the last encoder layer; 512 channels)
+    (640, 8, 128, 256), (320, 8, 256, 512),
 ]
 
 
@@ -252,7 +256,9 @@ DECONV_CASES = [(3, 4, 64, 32), (2, 8, 32, 16), (3, 16, 16, 8), (2, 32, 8, 4), (
                 (3, 2, 64, 32), (5, 2, 32, 16), (100, 32, 32, 16), (40, 32, 64, 32), (3, 16, 32, 16), (2, 16, 64, 32),
                 (300, 16, 32, 16), (70, 32, 64, 32),
                 # 128 -> 64 on 8-wide frames: one phase per workgroup, two rows per group of sixteen pixels
-                (3, 8, 128, 64), (300, 8, 128, 64)]
+                (3, 8, 128, 64), (300, 8, 128, 64),
+                # K shared out over two workgroups per tile (152 tiles of 128 x 128)
+                (300, 4, 256, 128)]
 
 
 @pytest.mark.parametrize('N,H,Cin,Cout', DECONV_CASES)
@@ -986,8 +992,9 @@ def test_dgrad_with_fused_bn_backward_statistics(ops, kind, N, H, Cin, Cout):
     aff = (dev(sc), dev(sh), dev(mean), dev(invstd))
     fn = ops.conv4s2_dgrad_bnstat if kind == 'conv' else ops.deconv4s2_dgrad_bnstat
     du, parts = fn(dev(nhwc(x)), wp, dev(y), aff)
-    assert torch.equal(du, plain)
-    du64 = plain.double().cpu()
+    # the plain entry point may share a long K loop out over several workgroups (another order of additions)
+    assert rel_err(du, plain) < 1e-6
+    du64 = du.double().cpu()
     z = y * sc + sh
     dz = du64 * torch.where(z > 0, 1.0, 0.2)
     xhat = (y - mean) * invstd
