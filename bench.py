@@ -40,7 +40,7 @@ GFLOP_PER_CLIP = {'disentangled_simple.json': (1.524, 4.571), 'lstm_simple.json'
 PRECISION_LABEL = {'fp32': ('f32', 'fp32 MFMA'),
                    'bf16': ('bf16', 'bf16 MFMA operands, fp32 accumulate and storage'),
                    'fp32_split': ('f32', 'fp32 products from a three-term bf16 split of each operand '
-                                         '(Linear layers), fp32 MFMA elsewhere')}
+                                         '(Linear layers, tiled convolutions), fp32 MFMA elsewhere')}
 
 
 def load_config(name):
@@ -434,9 +434,9 @@ def main():
             result['fp32_split_variant'] = {
                 'value': round(world * B * args.steps / el, 2), 'unit': 'clips/s',
                 'ms_per_step': round(el / args.steps * 1e3, 3), 'loss': round(float(out['total_loss'].item()), 3),
-                'workload': 'same training step with the Linear-layer GEMMs forming each fp32 product from six '
-                            'bf16 MFMA products of a three-term operand split (fp32-level error); not the headline '
-                            'value'}
+                'workload': 'same training step with the Linear-layer GEMMs and the tiled convolutions forming each fp32 '
+                            'product from six bf16 MFMA products of a three-term operand split (fp32-level error); '
+                            'not the headline value'}
             ops.set_precision('fp32')
         if args.config == 'disentangled_simple.json' and args.precision == 'fp32':
             # BASELINE configurations 2 and 3 (batch 32 on one GPU, fp32) and the small baseline beside them

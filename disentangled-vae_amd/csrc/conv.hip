@@ -259,7 +259,7 @@ struct ConvALoader {
   }
 };
 
-template <class T, int MODE, bool C1, bool BF, bool BNS>
+template <class T, int MODE, bool C1, int BF, bool BNS>      // BF: PREC_F32, PREC_BF16 or PREC_SPLIT
 __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * Core<T, BF>::STAGE];
   // transposed conv: the four sub-pixel phases of one M tile share its input tile.  Workgroups go to
@@ -1239,6 +1239,7 @@ template <int MODE>
 static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t stream) {
   const bool c1 = g.Cin == 1;
   const bool bf = dvae_mfma_precision() == DVAE_PRECISION_BF16;
+  const bool sp = dvae_mfma_precision() == DVAE_PRECISION_F32_SPLIT;     // tiled kernels without fused BN-backward sums
   const bool bns = g.bn_y != nullptr;
 #define LAUNCH(TILE, C1FLAG)                                                                         \
   {                                                                                                  \
@@ -1259,13 +1260,15 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     }                                                                                                \
     if (bns && !(C1FLAG)) {                                                                          \
       if (bf)                                                                                        \
-        DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, !(C1FLAG), !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
+        DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, (C1FLAG) ? PREC_F32 : PREC_BF16, !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
       else                                                                                           \
-        DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, false, !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
+        DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, PREC_F32, !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
     } else if (bf && !(C1FLAG))                                                                      \
-      DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, !(C1FLAG), false>), grid, dim3(256), 0, stream, g); \
+      DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, (C1FLAG) ? PREC_F32 : PREC_BF16, false>), grid, dim3(256), 0, stream, g); \
+    else if (sp && !(C1FLAG))                                                                        \
+      DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, (C1FLAG) ? PREC_F32 : PREC_SPLIT, false>), grid, dim3(256), 0, stream, g); \
     else                                                                                             \
-      DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, false, false>), grid, dim3(256), 0, stream, g); \
+      DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, PREC_F32, false>), grid, dim3(256), 0, stream, g); \
   }
   int mt_begin = 0, mt_end = -1;       // M-tile range of the next LAUNCH (-1: the whole layer)
   int ksplit = 1;                      // gridDim.z of the next LAUNCH

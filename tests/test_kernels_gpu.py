@@ -249,6 +249,26 @@ def test_conv4s2_fwd(ops, N, H, Cin, Cout):
     assert rel_err(s[1], (ref ** 2).sum(dim=(0, 2, 3))) < 1e-5
 
 
+@pytest.mark.parametrize('N,H,Cin,Cout', [(4, 8, 64, 128), (2, 8, 128, 256), (9, 4, 8, 4), (640, 8, 128, 256)])
+def test_conv4s2_fwd_in_split_precision_is_fp32_accurate(ops, N, H, Cin, Cout):
+    """the tiled kernels in 'fp32_split' mode (six bf16 MFMA products of a three-term split per fp32 product) keep
+    the fp32 bar of the plain kernels"""
+    x = rnd(N, Cin, H, H, seed=28)
+    w = rnd(Cout, Cin, 4, 4, seed=29, scale=0.2)
+    ref = F.conv2d(x, w, None, stride=2, padding=1)
+    wp = ops.pack_conv_w(dev(w))
+    ops.set_precision('fp32_split')
+    try:
+        y, stats, _ = ops.conv4s2_fwd(dev(nhwc(x)), None, None, ops.ACT_NONE, wp, True)
+        wt = rnd(Cout, Cin, 4, 4, seed=30, scale=0.2)
+        yt, _, _ = ops.deconv4s2_fwd(dev(nhwc(ref)), None, None, ops.ACT_NONE, ops.pack_deconv_w(dev(wt)), False)
+    finally:
+        ops.set_precision('fp32')
+    assert rel_err(nchw(y), ref) < 2e-6
+    assert rel_err(stats.double().sum(0).cpu()[1], (ref ** 2).sum(dim=(0, 2, 3))) < 1e-5
+    assert rel_err(nchw(yt), F.conv_transpose2d(ref, wt, None, stride=2, padding=1)) < 2e-6
+
+
 # (64,32) and (32,16) on frames at least 16 wide take the row-ring kernel: one and two groups of
 # sixteen pixels per row (H=16, 32), a single row per image never (H >= 16), and more workgroups than
 # share out the rows (N=70 at 64->32); the same channels on smaller frames take the tiled kernel
