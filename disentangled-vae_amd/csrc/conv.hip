@@ -1755,8 +1755,10 @@ struct WgradQLoader {
   }
 };
 
-template <class T, bool BF>
+template <class T, int PREC>      // PREC_F32, PREC_BF16 or PREC_SPLIT
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs g) {
+  constexpr int BF = PREC;
+  constexpr bool BFL = PREC == PREC_BF16;       // the loaders' bf16 chunk order
   __shared__ __attribute__((aligned(16))) float smem[2 * Core<T, BF>::STAGE];
   const int64_t m0 = (int64_t)blockIdx.y * T::BM, n0 = (int64_t)blockIdx.x * T::BN;
   const int ktiles = (int)((g.Mtot + 31) / 32);
@@ -1765,12 +1767,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs g) {
   if (kt_end > ktiles) kt_end = ktiles;
   f32x16 acc[T::TM][T::TN];
   zero_acc<T>(acc);
-  WgradPLoader<T::A_V4, T::BM, BF> la(g, m0);
-  WgradQLoader<T::B_V4, T::BN, BF> lb(g, n0);
+  WgradPLoader<T::A_V4, T::BM, BFL> la(g, m0);
+  WgradQLoader<T::B_V4, T::BN, BFL> lb(g, n0);
   // two K tiles of loads in flight: the narrow tiles multiply for less time than a load takes (+5 % on
   // the 64x128 tile), and the 128x128 tile gains 3-4 % with its light loaders (190 registers, no spill);
   // the bf16 variant of the wide tile keeps one tile in flight
-  if (T::TM * T::TN <= 2 || !BF) gemm_mainloop_ahead2<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
+  if (T::TM * T::TN <= 2 || PREC == PREC_F32) gemm_mainloop_ahead2<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
   else gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
   float* dst = g.slab + (int64_t)blockIdx.z * g.C1 * g.NC;
   for_each_acc<T>(acc, [&](int r, int c, float v) {
@@ -2594,8 +2596,10 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
     const dim3 grid((unsigned)p.tn, (unsigned)p.tm, (unsigned)p.split);
     const bool bf = dvae_mfma_precision() == DVAE_PRECISION_BF16;
 #define WG_LAUNCH(TILE)                                                                     \
-  if (bf) DVAE_LAUNCH((conv_wgrad_kernel<TILE, true>), grid, dim3(256), 0, s, g);     \
-  else DVAE_LAUNCH((conv_wgrad_kernel<TILE, false>), grid, dim3(256), 0, s, g);
+  if (bf) DVAE_LAUNCH((conv_wgrad_kernel<TILE, PREC_BF16>), grid, dim3(256), 0, s, g);     \
+  else if (dvae_mfma_precision() == DVAE_PRECISION_F32_SPLIT)                              \
+    DVAE_LAUNCH((conv_wgrad_kernel<TILE, PREC_SPLIT>), grid, dim3(256), 0, s, g);          \
+  else DVAE_LAUNCH((conv_wgrad_kernel<TILE, PREC_F32>), grid, dim3(256), 0, s, g);
     typedef Tile<32, 128, 1, 4, false, false> W32;
     typedef Tile<64, 128, 2, 2, false, false> W64;
     typedef Tile<128, 128, 2, 2, false, false> W128;

@@ -339,6 +339,21 @@ def test_conv4s2_wgrad(ops, N, Hs, C1, C2):
     assert rel_err(got, dw) < 5e-6
 
 
+@pytest.mark.parametrize('N,Hs,C1,C2', [(3, 8, 64, 32), (3, 2, 256, 128), (9, 8, 256, 256), (40, 16, 16, 8)])
+def test_conv4s2_wgrad_in_split_precision_is_fp32_accurate(ops, N, Hs, C1, C2):
+    """the tiled weight-gradient kernel in 'fp32_split' mode keeps the fp32 bar"""
+    x = rnd(N, C2, 2 * Hs, 2 * Hs, seed=35)
+    dy = rnd(N, C1, Hs, Hs, seed=36)
+    w = torch.zeros(C1, C2, 4, 4, dtype=torch.float64, requires_grad=True)
+    (dw,) = torch.autograd.grad(F.conv2d(x, w, None, stride=2, padding=1), w, dy)
+    ops.set_precision('fp32_split')
+    try:
+        got = ops.conv4s2_wgrad(dev(nhwc(dy)), None, None, ops.ACT_NONE, dev(nhwc(x)), None, None, ops.ACT_NONE)
+    finally:
+        ops.set_precision('fp32')
+    assert rel_err(got, dw) < 5e-6
+
+
 @pytest.mark.parametrize('N,H,Cin,Cout', [(3, 8, 16, 8), (3, 16, 64, 32), (2, 16, 32, 16), (5, 8, 128, 64), (40, 4, 256, 128)])
 def test_wgrad_for_transposed_conv(ops, N, H, Cin, Cout):
     # ConvTranspose2d weight gradient: P = layer input (with load transform), Q = dY
