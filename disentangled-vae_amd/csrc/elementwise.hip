@@ -1067,10 +1067,9 @@ colsum_kernel(float* __restrict__ du, const float* __restrict__ y, const float* 
     is = *reinterpret_cast<const float4*>(invstd + c);
   }
   if (col_ok) {
-    for (int64_t r = (int64_t)blockIdx.x * ty + ry; r < M; r += (int64_t)gridDim.x * ty) {
-      float4 g = *reinterpret_cast<const float4*>(du + r * C + c);
+    // one row's contribution; rows are added in ascending order whatever the unrolling, so the sums do not depend on it
+    auto add_row = [&](int64_t r, float4 g, const float4 yv) {
       if (MODE == 0) {
-        const float4 yv = *reinterpret_cast<const float4*>(y + r * C + c);
         const float z0 = fmaf(yv.x, sc.x, sh.x), z1 = fmaf(yv.y, sc.y, sh.y), z2 = fmaf(yv.z, sc.z, sh.z),
                     z3 = fmaf(yv.w, sc.w, sh.w);
         const float d0 = z0 > 0.f ? g.x : g.x * LRELU_SLOPE, d1 = z1 > 0.f ? g.y : g.y * LRELU_SLOPE,
@@ -1082,15 +1081,33 @@ colsum_kernel(float* __restrict__ du, const float* __restrict__ y, const float* 
         a2[3] += d3 * ((yv.w - mu.w) * is.w);
       } else {
         if (act == DVAE_ACT_LRELU) {
-          const float4 o = *reinterpret_cast<const float4*>(y + r * C + c);
-          g.x = o.x > 0.f ? g.x : g.x * LRELU_SLOPE;
-          g.y = o.y > 0.f ? g.y : g.y * LRELU_SLOPE;
-          g.z = o.z > 0.f ? g.z : g.z * LRELU_SLOPE;
-          g.w = o.w > 0.f ? g.w : g.w * LRELU_SLOPE;
+          g.x = yv.x > 0.f ? g.x : g.x * LRELU_SLOPE;
+          g.y = yv.y > 0.f ? g.y : g.y * LRELU_SLOPE;
+          g.z = yv.z > 0.f ? g.z : g.z * LRELU_SLOPE;
+          g.w = yv.w > 0.f ? g.w : g.w * LRELU_SLOPE;
           *reinterpret_cast<float4*>(du + r * C + c) = g;
         }
         a1[0] += g.x; a1[1] += g.y; a1[2] += g.z; a1[3] += g.w;
       }
+    };
+    const bool need_y = MODE == 0 || act == DVAE_ACT_LRELU;
+    const int64_t step = (int64_t)gridDim.x * ty;
+    int64_t r = (int64_t)blockIdx.x * ty + ry;
+    // four rows' loads in flight per thread: with one, the loop runs at the latency of a load, not at bandwidth
+    for (; r + 3 * step < M; r += 4 * step) {
+      float4 g[4], yv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        g[u] = *reinterpret_cast<const float4*>(du + (r + u * step) * C + c);
+        yv[u] = need_y ? *reinterpret_cast<const float4*>(y + (r + u * step) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) add_row(r + u * step, g[u], yv[u]);
+    }
+    for (; r < M; r += step) {
+      const float4 g = *reinterpret_cast<const float4*>(du + r * C + c);
+      const float4 yv = need_y ? *reinterpret_cast<const float4*>(y + r * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      add_row(r, g, yv);
     }
   }
   // reduce over ry
@@ -1171,6 +1188,7 @@ extern "C" int dvae_bn_bwd_coeffs_f32(const float* partials, int64_t nparts, con
 // dx = scale * (dz - dbeta/M - xhat * dgamma/M), dz = du * lrelu'(scale*y + shift), in place over du.
 // The launch makes the grid stride a multiple of C/4, so a thread meets the same four channels in
 // every iteration and keeps their six constants in registers.
+template <bool ADJ>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(float4* __restrict__ du, const float4* __restrict__ y, const float* __restrict__ scale,
                     const float* __restrict__ shift, const float* __restrict__ mean,
@@ -1186,10 +1204,6 @@ bn_bwd_apply_kernel(float4* __restrict__ du, const float4* __restrict__ y, const
   float4 k2 = *reinterpret_cast<const float4*>(dgamma + c);     // dgamma/M
   k1.x *= invM; k1.y *= invM; k1.z *= invM; k1.w *= invM;
   k2.x *= invM; k2.y *= invM; k2.z *= invM; k2.w *= invM;
-  for (int64_t i = first; i < total4; i += stride) {
-    const float4 g = du[i];
-    const float4 yv = y[i];
-    float4 o;
 #define BN_ONE(f)                                                         \
   {                                                                       \
     const float z = fmaf(yv.f, sc.f, sh.f);                               \
@@ -1197,10 +1211,60 @@ bn_bwd_apply_kernel(float4* __restrict__ du, const float4* __restrict__ y, const
     const float xh = (yv.f - mu.f) * is.f;                                \
     o.f = sc.f * (dz - k1.f - xh * k2.f);                                 \
   }
+  int64_t i = first;
+  if (ADJ) {
+    // a workgroup takes four adjacent 4 KB pieces per round (256 % C4 == 0 keeps a thread on its channels)
+    int64_t j = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    for (; j + 768 < total4; j += 4 * stride) {
+      float4 gs[4], ys[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        gs[u] = du[j + u * 256];
+        ys[u] = y[j + u * 256];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 g = gs[u], yv = ys[u];
+        float4 o;
+        BN_ONE(x) BN_ONE(y) BN_ONE(z) BN_ONE(w)
+        du[j + u * 256] = o;
+      }
+    }
+    // the ragged last round of the one workgroup that meets the end
+    for (int u = 0; u < 4; ++u)
+      if (j + u * 256 < total4) {
+        const float4 g = du[j + u * 256];
+        const float4 yv = y[j + u * 256];
+        float4 o;
+        BN_ONE(x) BN_ONE(y) BN_ONE(z) BN_ONE(w)
+        du[j + u * 256] = o;
+      }
+    i = total4;
+  }
+  // four elements' loads in flight per thread before the first is used
+  for (; i + 3 * stride < total4; i += 4 * stride) {
+    float4 gs[4], ys[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      gs[u] = du[i + u * stride];
+      ys[u] = y[i + u * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4 g = gs[u], yv = ys[u];
+      float4 o;
+      BN_ONE(x) BN_ONE(y) BN_ONE(z) BN_ONE(w)
+      du[i + u * stride] = o;
+    }
+  }
+  for (; i < total4; i += stride) {
+    const float4 g = du[i];
+    const float4 yv = y[i];
+    float4 o;
     BN_ONE(x) BN_ONE(y) BN_ONE(z) BN_ONE(w)
-#undef BN_ONE
     du[i] = o;
   }
+#undef BN_ONE
 }
 
 // grid of the apply kernel: at most 4096 workgroups, and 256 * gridDim.x a multiple of C/4
@@ -1218,6 +1282,12 @@ static unsigned bn_apply_blocks(int64_t total4, int64_t C4) {
   return (unsigned)nb;
 }
 
+// adjacent pieces per workgroup need a thread to stay on its four channels from one 256-element piece to the next
+static bool bn_apply_adj(int64_t C4) { return 256 % C4 == 0; }
+#define DVAE_LAUNCH_BN_APPLY(nb, ...)                                                         \
+  if (bn_apply_adj(C / 4)) DVAE_LAUNCH(bn_bwd_apply_kernel<true>, dim3(nb), __VA_ARGS__);   \
+  else DVAE_LAUNCH(bn_bwd_apply_kernel<false>, dim3(nb), __VA_ARGS__)
+
 extern "C" int dvae_bn_bwd_f32(float* du, const float* y, const float* scale, const float* shift, const float* mean,
                                const float* invstd, const float* gamma, float* dgamma, float* dbeta, float* ws,
                                int64_t M, int64_t C, dvae_stream_t stream) {
@@ -1233,7 +1303,7 @@ extern "C" int dvae_bn_bwd_f32(float* du, const float* y, const float* scale, co
   DVAE_LAUNCH_CHECK("bn_bwd_finalize");
   const int64_t total4 = M * C / 4;
   DVAE_WORK(12.0 * (double)M * C, DVAE_UNIT_BYTE);                         // du, y in; dy out
-  DVAE_LAUNCH(bn_bwd_apply_kernel, dim3(bn_apply_blocks(total4, C / 4)), dim3(256), 0, ST(stream), (float4*)du, (const float4*)y,
+  DVAE_LAUNCH_BN_APPLY(bn_apply_blocks(total4, C / 4), dim3(256), 0, ST(stream), (float4*)du, (const float4*)y,
                      scale, shift, mean, invstd, (const float*)dbeta, (const float*)dgamma, 1.f / (float)M, total4,
                      (int)(C / 4));
   DVAE_LAUNCH_CHECK("bn_bwd_apply");
@@ -1266,7 +1336,7 @@ extern "C" int dvae_bn_bwd_from_partials_f32(float* du, const float* y, const fl
   DVAE_LAUNCH_CHECK("bn_bwd_finalize");
   const int64_t total4 = M * C / 4;
   DVAE_WORK(12.0 * (double)M * C, DVAE_UNIT_BYTE);                         // du, y in; dy out
-  DVAE_LAUNCH(bn_bwd_apply_kernel, dim3(bn_apply_blocks(total4, C / 4)), dim3(256), 0, ST(stream), (float4*)du, (const float4*)y,
+  DVAE_LAUNCH_BN_APPLY(bn_apply_blocks(total4, C / 4), dim3(256), 0, ST(stream), (float4*)du, (const float4*)y,
                      scale, shift, mean, invstd, (const float*)dbeta, (const float*)dgamma, 1.f / (float)M, total4,
                      (int)(C / 4));
   DVAE_LAUNCH_CHECK("bn_bwd_apply");

@@ -11,7 +11,9 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libdvae_hip.so')
+# DVAE_HIP_LIB names another build of the same library (A/B of two builds in one session); the default is the
+# in-tree one
+LIB_PATH = os.environ.get('DVAE_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'libdvae_hip.so')
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

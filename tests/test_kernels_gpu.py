@@ -381,7 +381,8 @@ def test_deconv_final(ops, N, H, Cin):
 
 
 # ------------------------------------------------------------------ BatchNorm glue
-@pytest.mark.parametrize('M,C', [(4 * 32 * 32, 16), (640 * 16, 128), (37, 4), (2000, 512)])
+@pytest.mark.parametrize('M,C', [(4 * 32 * 32, 16), (640 * 16, 128), (37, 4), (2000, 512), (4099, 8), (5003, 12),
+                                 (70001, 256)])
 def test_bn_forward_backward(ops, M, C):
     y = rnd(M, C, seed=44) * (1 + rnd(C, seed=45).abs()) + rnd(C, seed=46)
     gamma, beta = 1 + 0.2 * rnd(C, seed=47), 0.1 * rnd(C, seed=48)
