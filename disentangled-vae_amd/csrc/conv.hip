@@ -69,6 +69,69 @@ extern "C" int dvae_pack_deconv_w_f32(const float* w, float* wp, int64_t Kc, int
   return 0;
 }
 
+// Several weights in one launch: a step packs every convolution weight of an encoder or decoder (both layouts when
+// a backward follows), and at small batch sizes sixteen few-microsecond launches cost more than the packing.
+#define PACK_MAX 16
+#define PACK_PER_BLOCK 2048          // elements a workgroup packs
+struct PackTable {
+  int first_block[PACK_MAX + 1];
+  const float* w[PACK_MAX];
+  float* wp[PACK_MAX];
+  int64_t d0[PACK_MAX], d1[PACK_MAX];
+  int transposed[PACK_MAX];
+  int n;
+};
+
+__global__ void __launch_bounds__(256) pack_many_kernel(PackTable t) {
+  int it = 0;
+  while (it + 1 < t.n && (int)blockIdx.x >= t.first_block[it + 1]) ++it;
+  const int64_t lo = (int64_t)(blockIdx.x - t.first_block[it]) * PACK_PER_BLOCK;
+  const float* __restrict__ w = t.w[it];
+  float* __restrict__ wp = t.wp[it];
+  const int64_t d0 = t.d0[it], d1 = t.d1[it];
+  const int64_t total = d0 * d1 * 16 < lo + PACK_PER_BLOCK ? d0 * d1 * 16 : lo + PACK_PER_BLOCK;
+  if (!t.transposed[it]) {
+    for (int64_t i = lo + threadIdx.x; i < total; i += 256) {
+      const int64_t b = i % d1, tp = (i / d1) % 16, a = i / (d1 * 16);
+      wp[i] = w[(a * d1 + b) * 16 + tp];
+    }
+  } else {
+    const int64_t per_phase = d1 * 4 * d0;
+    for (int64_t i = lo + threadIdx.x; i < total; i += 256) {
+      const int64_t k = i % d0, tap = (i / d0) % 4, n = (i / (d0 * 4)) % d1, phase = i / per_phase;
+      const int ph = (int)(phase >> 1), pw = (int)(phase & 1), th = (int)(tap >> 1), tw = (int)(tap & 1);
+      const int kh = ph == 0 ? (th == 0 ? 1 : 3) : (th == 0 ? 0 : 2);
+      const int kw = pw == 0 ? (tw == 0 ? 1 : 3) : (tw == 0 ? 0 : 2);
+      wp[i] = w[((k * d1 + n) * 4 + kh) * 4 + kw];
+    }
+  }
+}
+
+extern "C" int dvae_pack_w_many_f32(int n, const float* const* w, float* const* wp, const int64_t* d0,
+                                    const int64_t* d1, const int* transposed, dvae_stream_t stream) {
+  DVAE_REQUIRE(n >= 0 && w && wp && d0 && d1 && transposed, "pack_w_many: null table");
+  for (int i = 0; i < n; ++i)
+    DVAE_REQUIRE(w[i] && wp[i] && d0[i] > 0 && d1[i] > 0, "pack_w_many: item %d is empty", i);
+  for (int first = 0; first < n; first += PACK_MAX) {
+    PackTable t;
+    t.n = n - first < PACK_MAX ? n - first : PACK_MAX;
+    t.first_block[0] = 0;
+    for (int i = 0; i < t.n; ++i) {
+      const int64_t blocks = ceil_div64(d0[first + i] * d1[first + i] * 16, PACK_PER_BLOCK);
+      DVAE_REQUIRE(blocks < (1 << 24), "pack_w_many: item %d is too large", first + i);
+      t.first_block[i + 1] = t.first_block[i] + (int)blocks;
+      t.w[i] = w[first + i];
+      t.wp[i] = wp[first + i];
+      t.d0[i] = d0[first + i];
+      t.d1[i] = d1[first + i];
+      t.transposed[i] = transposed[first + i];
+    }
+    DVAE_LAUNCH(pack_many_kernel, dim3((unsigned)t.first_block[t.n]), dim3(256), 0, ST(stream), t);
+    DVAE_LAUNCH_CHECK("pack_w_many");
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward kernels
 // ------------------------------------------------------------------------------------------------

@@ -69,6 +69,7 @@ SIGNATURES = {
     'dvae_gemm_tn_f32': (I, [P, L, P, L, P, L, L, L, L, I, P, P]),
     'dvae_pack_conv_w_f32': (I, [P, P, L, L, P]),
     'dvae_pack_deconv_w_f32': (I, [P, P, L, L, P]),
+    'dvae_pack_w_many_f32': (I, [I, P, P, P, P, P, P]),
     'dvae_conv_stat_parts': (L, [L]),
     'dvae_conv_stat_parts_written': (L, [L, I]),
     'dvae_conv4s2_fwd_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P]),

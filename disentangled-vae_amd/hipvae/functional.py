@@ -169,9 +169,14 @@ class EncoderCNN(torch.autograd.Function):
         conv_w, gammas, betas = wgb[:L], wgb[L:2 * L], wgb[2 * L:3 * L]
         ys, affs = [], []
         cur, sc, sh, act = x.contiguous(), None, None, ops.ACT_NONE
+        # every layer's weight in the layout its kernel reads, and (when a backward follows) in the transposed
+        # layout its data gradient reads, all packed by one launch
+        need_bwd = training and any(ctx.needs_input_grad)
+        packs = ops.pack_many([(w.detach(), False) for w in conv_w]
+                              + ([(w.detach(), True) for w in conv_w[1:]] if need_bwd else []))
+        ctx.wpd = [None] + packs[L:]
         for l in range(L):
-            wp = ops.pack_conv_w(conv_w[l].detach())
-            y, stats, nparts = ops.conv4s2_fwd(cur, sc, sh, act, wp, training)
+            y, stats, nparts = ops.conv4s2_fwd(cur, sc, sh, act, packs[l], training)
             M = y.numel() // y.shape[-1]
             aff = _bn_affine(stats, nparts, M, gammas[l].detach(), betas[l].detach(), bns[l], training)
             ys.append(y)
@@ -232,7 +237,7 @@ class EncoderCNN(torch.autograd.Function):
                 if parts is None:
                     parts = ops.bn_bwd_reduce(du, ys[l], affs[l])
                 d_gamma[l], d_beta[l], ca, cb = ops.bn_bwd_coeffs(parts, affs[l], M)
-                wpd = ops.pack_deconv_w(conv_w[l])
+                wpd = ctx.wpd[l]
                 du, parts, dy = ops.deconv4s2_dgrad_bnstat_bnin(du, ys[l], affs[l], ca, cb, wpd, ys[l - 1], affs[l - 1])
                 psc, psh = affs[l - 1][0], affs[l - 1][1]
                 d_conv[l] = off.run(lambda dy=dy, l=l, psc=psc, psh=psh: ops.conv4s2_wgrad(
@@ -244,7 +249,7 @@ class EncoderCNN(torch.autograd.Function):
                 psc, psh = affs[l - 1][0], affs[l - 1][1]
                 d_conv[l] = off.run(lambda dy=dy, l=l, psc=psc, psh=psh: ops.conv4s2_wgrad(
                     dy, None, None, ops.ACT_NONE, ys[l - 1], psc, psh, ops.ACT_LRELU), dy)
-                wpd = ops.pack_deconv_w(conv_w[l])
+                wpd = ctx.wpd[l]
                 if _fuse_bn_stats(ys[l - 1].shape[-1]):
                     du, parts = ops.deconv4s2_dgrad_bnstat(dy, wpd, ys[l - 1], affs[l - 1])
                 else:
@@ -320,9 +325,12 @@ class DecoderCNN(torch.autograd.Function):
         cur = h0.view(N, 4, 4, C0)
         sc, sh, act = None, None, ops.ACT_NONE
         ys, affs = [], []
+        need_bwd = training and any(ctx.needs_input_grad)
+        packs = ops.pack_many([(w.detach(), True) for w in dec_w]
+                              + ([(w.detach(), False) for w in dec_w] if need_bwd else []))   # as in EncoderCNN
+        ctx.wp = packs[L:]
         for l in range(L):
-            wpd = ops.pack_deconv_w(dec_w[l].detach())
-            y, stats, nparts = ops.deconv4s2_fwd(cur, sc, sh, act, wpd, training)
+            y, stats, nparts = ops.deconv4s2_fwd(cur, sc, sh, act, packs[l], training)
             M = y.numel() // y.shape[-1]
             aff = _bn_affine(stats, nparts, M, gammas[l].detach(), betas[l].detach(), bns[l], training, replicas)
             ys.append(y)
@@ -383,7 +391,7 @@ class DecoderCNN(torch.autograd.Function):
         d_dec, d_gamma, d_beta = [None] * L, [None] * L, [None] * L
         for l in range(L - 1, -1, -1):
             sc, sh, mean, invstd = affs[l]
-            wp = ops.pack_conv_w(dec_w[l])        # [Cin_d][4][4][Cout_d]: the adjoint is a plain conv
+            wp = ctx.wp[l]                        # [Cin_d][4][4][Cout_d]: the adjoint is a plain conv
             if l > 0:
                 pin, psc, psh, pact = ys[l - 1], affs[l - 1][0], affs[l - 1][1], ops.ACT_LRELU
             else:

@@ -5,6 +5,7 @@ torch's current stream.  PyTorch is used for device memory and streams only; the
 alternative code path: a CPU tensor is an error.
 """
 import ctypes
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -449,6 +450,32 @@ def pack_deconv_w(w: Tensor) -> Tensor:
     wp = torch.empty(4, Nc, 2, 2, Kc, dtype=torch.float32, device=w.device)
     check(lib.dvae_pack_deconv_w_f32(_p(w), _p(wp), Kc, Nc, _stream()), 'pack_deconv_w')
     return wp
+
+
+# DVAE_PACK_MANY=0: one launch per weight (for A/B measurements)
+PACK_IN_ONE_LAUNCH = os.environ.get('DVAE_PACK_MANY', '1') != '0'
+
+
+def pack_many(items) -> list:
+    """items: [(weight, transposed)]; -> the packed weights, pack_conv_w(weight) where transposed is false and
+    pack_deconv_w(weight) where it is true, all written by one launch."""
+    if not items:
+        return []
+    if not PACK_IN_ONE_LAUNCH:
+        return [pack_deconv_w(w) if tr else pack_conv_w(w) for w, tr in items]
+    ws = [w for w, _ in items]
+    _chk(*ws)
+    n = len(items)
+    outs = []
+    for w, tr in items:
+        d0, d1 = w.shape[:2]
+        shape = (4, d1, 2, 2, d0) if tr else (d0, 4, 4, d1)
+        outs.append(torch.empty(*shape, dtype=torch.float32, device=w.device))
+    PA, LA, IA = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    check(lib.dvae_pack_w_many_f32(n, PA(*[w.data_ptr() for w in ws]), PA(*[o.data_ptr() for o in outs]),
+                                   LA(*[w.shape[0] for w in ws]), LA(*[w.shape[1] for w in ws]),
+                                   IA(*[1 if tr else 0 for _, tr in items]), _stream()), 'pack_w_many')
+    return outs
 
 
 def conv4s2_fwd(x: Tensor, scale, shift, act: int, wp: Tensor, want_stats: bool):

@@ -243,6 +243,13 @@ int dvae_pack_conv_w_f32(const float* w, float* wp, int64_t A, int64_t Bc, dvae_
 /* torch weight [Kc][Nc][4][4] -> [phase=ph*2+pw][Nc][th][tw][Kc], the four 2x2 sub-pixel filters of
  * the transposed convolution (kh = 1,3 for even output rows, 0,2 for odd ones). */
 int dvae_pack_deconv_w_f32(const float* w, float* wp, int64_t Kc, int64_t Nc, dvae_stream_t stream);
+
+/* n weights packed in ONE launch (per 16): item i is dvae_pack_conv_w_f32(w[i], wp[i], d0[i], d1[i]) when
+ * transposed[i] == 0, dvae_pack_deconv_w_f32(w[i], wp[i], d0[i], d1[i]) otherwise.  The arrays are host arrays,
+ * read during the call.  The reference packs nothing (torch keeps OIHW weights, models/encoders.py:33-38,
+ * models/decoders.py:36-42); one call per encoder/decoder forward replaces its per-layer calls. */
+int dvae_pack_w_many_f32(int n, const float* const* w, float* const* wp, const int64_t* d0, const int64_t* d1,
+                         const int* transposed, dvae_stream_t stream);
 int64_t dvae_conv_stat_parts(int64_t M_rows);
 /* exact number of partial rows a forward launch with that many GEMM rows per phase writes
  * (phases = 1 for the convolution, 4 for the transposed convolution) */

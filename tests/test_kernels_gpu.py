@@ -380,6 +380,22 @@ def test_deconv_final(ops, N, H, Cin):
     torch.testing.assert_close(got.cpu().double(), ref, rtol=1e-5, atol=1e-6)
 
 
+def test_pack_many_is_the_single_packs_in_one_launch(ops):
+    """20 weights (more than one table holds), both layouts, sizes from 1 to 256 channels: bit-equal to the
+    per-weight packs, which the convolution tests pin against torch."""
+    shapes = [(32, 1), (64, 32), (128, 64), (256, 128), (5, 3), (1, 1), (7, 130), (256, 256), (16, 8), (2, 67)]
+    items = []
+    for i, (a, b) in enumerate(shapes):
+        w = dev(rnd(a, b, 4, 4, seed=900 + i).float())
+        items += [(w, False), (w, True)]
+    got = ops.pack_many(items)
+    assert len(got) == len(items)
+    for (w, tr), g in zip(items, got):
+        want = ops.pack_deconv_w(w) if tr else ops.pack_conv_w(w)
+        assert g.shape == want.shape and torch.equal(g, want)
+    assert ops.pack_many([]) == []
+
+
 # ------------------------------------------------------------------ BatchNorm glue
 @pytest.mark.parametrize('M,C', [(4 * 32 * 32, 16), (640 * 16, 128), (37, 4), (2000, 512), (4099, 8), (5003, 12),
                                  (70001, 256)])
