@@ -300,7 +300,15 @@ static int launch_gemm(const char* name, GemmArgs g, float* ws, hipStream_t stre
       return 0;
     }
   }
+  // A launch takes as long as the busiest CU: ceil(tiles / 256) tiles of 128 x 128.  Tiles half as wide halve the
+  // unit (at a little less reuse per tile), which shortens launches of one to two tiles per CU: 304 tiles are
+  // two rounds of wide tiles but three half-rounds of narrow ones.
+  typedef Tile<128, 64, 4, 1, AKC, BKC> Half;
+  const int64_t wide_rounds = (tiles + 255) / 256, half_rounds = (2 * tiles + 255) / 256;
+  const bool narrow = !p.small_m && p.split == 1 && g.N % 64 == 0 &&
+                      1.08 * 0.5 * (double)half_rounds < 0.95 * (double)wide_rounds;
   if (p.small_m) GEMM_LAUNCH(Skinny, KIND, grid)
+  else if (narrow) GEMM_LAUNCH(Half, KIND, dim3((unsigned)ceil_div64(g.N, 64), (unsigned)p.tm, 1))
   else GEMM_LAUNCH(Big, KIND, grid)
 #undef GEMM_LAUNCH
   DVAE_LAUNCH_CHECK(name);

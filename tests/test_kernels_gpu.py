@@ -130,7 +130,9 @@ def test_independence(ops, B, Dc, Dm):
 
 # ------------------------------------------------------------------ GEMMs
 GEMM_SHAPES = [(32, 128, 512), (4, 32, 2048), (24, 64, 32), (608, 512, 8192 // 4), (130, 260, 36),
-               (640, 4096 // 4, 640), (256, 128, 4096), (1, 4, 4)]
+               (640, 4096 // 4, 640), (256, 128, 4096), (1, 4, 4),
+               # 304 tiles of 128 x 128: between one and two per CU, computed with 128 x 64 tiles
+               (4864, 1024, 64), (4837, 960, 36)]
 
 
 @pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
