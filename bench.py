@@ -146,7 +146,7 @@ def pmc_traffic(label):
     (profiles/*pmc_traffic.json: separate rocprofv3 --pmc passes of this same command; counters cannot
     be collected inside a timed run).  (None, None) when there is no entry."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_traffic.json')))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', '*pmc_traffic.json')) if 'bf16' not in f)
     if not files:
         return None, None
     try:
@@ -156,6 +156,25 @@ def pmc_traffic(label):
     if not entry:
         return None, None
     return entry['hbm_bytes_per_launch'], os.path.relpath(files[-1], ROOT)
+
+
+def hbm_floor(ms_per_step, bf16):
+    """The step against the HBM roofline: bytes one step moved through HBM (every kernel's FETCH_SIZE/WRITE_SIZE
+    counters from the newest committed counter summary of this command, fp32 or bf16 variant) / 8 TB/s, as a fraction
+    of the measured step.  None without such a summary."""
+    import glob
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', '*pmc_traffic.json')) if ('bf16' in f) == bf16)
+    for f in reversed(files):
+        try:
+            nbytes = json.load(open(f)).get('hbm_bytes_per_step')
+        except (OSError, ValueError):
+            continue
+        if nbytes:
+            floor_ms = nbytes / (PEAK_HBM_GBS * 1e9) * 1e3
+            return {'bound': 'hbm', 'traffic': nbytes, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                    'achieved': round(nbytes / (ms_per_step * 1e-3) / 1e9, 1), 'floor_ms': round(floor_ms, 3),
+                    'frac': round(floor_ms / ms_per_step, 4), 'traffic_source': os.path.relpath(f, ROOT)}
+    return None
 
 
 # --------------------------------------------------------------------------------------------
@@ -390,6 +409,9 @@ def main():
         whole = {'achieved': round(tfl, 2), 'peak': peak_tflops * world, 'unit': 'TFLOP/s',
                  'frac': round(tfl / (peak_tflops * world), 4),
                  'gflop_per_clip': gf[1 if args.mode == 'train' else 0]}
+        if args.mode == 'train' and kind == 'disentangled' and B == 256 and args.precision in ('fp32', 'bf16'):
+            # the same step against the other roof (counter bytes of the committed profile of this configuration)
+            whole['hbm'] = hbm_floor(elapsed / args.steps * 1e3, bf16=args.precision == 'bf16')
     if rank == 0 and world == 1 and not args.no_kernel_table:
         step = train_step if args.mode == 'train' else infer_step      # kernels are timed on eager launches
         # ... of one stream: with the weight gradients on their second stream a launch's events would also
@@ -429,6 +451,9 @@ def main():
                                       'loss': round(float(out['total_loss'].item()), 3),
                                       'workload': 'same training step with bf16 MFMA operands (fp32 accumulate, '
                                                   'fp32 tensors); not the headline value'}
+            if kind == 'disentangled' and B == 256 and size == 64 and T == 20:
+                # the bf16 step is bound by its bytes, not by the matrix pipe: priced against HBM
+                result['bf16_variant']['roofline'] = hbm_floor(result['bf16_variant']['ms_per_step'], bf16=True)
             ops.set_precision('fp32_split')
             el, out = measure(make_train_step(), args.steps, args.warmup)
             result['fp32_split_variant'] = {

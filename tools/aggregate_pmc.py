@@ -1,6 +1,7 @@
 """Aggregate rocprofv3 --pmc counter_collection CSVs per kernel symbol.
 
-usage: python tools/aggregate_pmc.py <dir with *_counter_collection.csv> [<dir> ...] > table.md
+usage: python tools/aggregate_pmc.py <dir with *_counter_collection.csv> [<dir> ...] [--json=out.json] [--steps=N] > table.md
+--steps: the steps the profiled command ran (warm-up included); adds the HBM bytes of one step, all kernels, to the JSON
 Counters are summed over dispatches of the same kernel; derived columns:
   mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 CUs * 4 SIMDs)   (GUI_ACTIVE is summed over 8 XCDs)
   hbm bytes = 2*FETCH_SIZE*1024 (gfx950 reports half the bytes of wide streaming reads) + WRITE_SIZE*1024
@@ -22,8 +23,9 @@ def bench_label(name):
 def main():
     agg = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(lambda: defaultdict(int))
-    args = [a for a in sys.argv[1:] if not a.startswith('--json=')]
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
     json_out = [a[7:] for a in sys.argv[1:] if a.startswith('--json=')]
+    steps = [int(a[8:]) for a in sys.argv[1:] if a.startswith('--steps=')]      # steps the profiled command ran
     for d in args:
         for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
             for r in csv.DictReader(open(f)):
@@ -66,7 +68,11 @@ def main():
                            'bench.py --steps 2 --warmup 1 --graph 0; read bytes = 2 x FETCH_SIZE x 1024 (gfx950 '
                            'reports half the bytes of wide streaming reads), write bytes = WRITE_SIZE x 1024; '
                            'per launch = summed over the dispatches of the kernel / their number',
-                   'kernels': out}, open(json_out[0], 'w'), indent=1, sort_keys=True)
+                   'kernels': out,
+                   'hbm_bytes_per_step': (round(sum(e['hbm_read_bytes'] + e['hbm_write_bytes'] for e in table.values())
+                                                / steps[0]) if steps else None),
+                   'steps_profiled': steps[0] if steps else None},
+                  open(json_out[0], 'w'), indent=1, sort_keys=True)
     print('| kernel | dispatches | MFMA busy / (active cycles x SIMDs) | f32 MFMA MOPS per dispatch | HBM read B/dispatch (2xFETCH_SIZE) | HBM write B/dispatch |')
     print('|---|---|---|---|---|---|')
     for gui, k, n, util, mops, rd, wr in rows[:40]:
