@@ -1046,12 +1046,12 @@ extern "C" int64_t dvae_colsum_ws_floats(int64_t M, int64_t C) {
 }
 
 // MODE 0: BN backward stats: v1 = dz, v2 = dz * xhat   (NV = 2)
-// MODE 1: bias/activation backward: dpre = dout*act'(out) written in place, v1 = dpre (NV = 1)
+// MODE 1: bias/activation backward: dpre = dout*act'(out) written to dst (which may be du itself), v1 = dpre (NV = 1)
 template <int MODE>
 __global__ void __launch_bounds__(256)
-colsum_kernel(float* __restrict__ du, const float* __restrict__ y, const float* __restrict__ scale,
+colsum_kernel(const float* du, const float* __restrict__ y, const float* __restrict__ scale,
               const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
-              int act, float* __restrict__ partials, int64_t M, int64_t C, int tx, int ty) {
+              int act, float* __restrict__ partials, int64_t M, int64_t C, int tx, int ty, float* dst) {
   constexpr int NV = MODE == 0 ? 2 : 1;
   __shared__ float red[256 * 4 * NV];
   const int cx = threadIdx.x % tx, ry = threadIdx.x / tx;
@@ -1085,8 +1085,8 @@ colsum_kernel(float* __restrict__ du, const float* __restrict__ y, const float* 
           g.y = yv.y > 0.f ? g.y : g.y * LRELU_SLOPE;
           g.z = yv.z > 0.f ? g.z : g.z * LRELU_SLOPE;
           g.w = yv.w > 0.f ? g.w : g.w * LRELU_SLOPE;
-          *reinterpret_cast<float4*>(du + r * C + c) = g;
         }
+        if (act == DVAE_ACT_LRELU || dst != du) *reinterpret_cast<float4*>(dst + r * C + c) = g;
         a1[0] += g.x; a1[1] += g.y; a1[2] += g.z; a1[3] += g.w;
       }
     };
@@ -1295,8 +1295,8 @@ extern "C" int dvae_bn_bwd_f32(float* du, const float* y, const float* scale, co
   DVAE_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd: need C%%4==0 (C=%ld)", (long)C);
   const ColsumGeom g = colsum_geom(M, C);
   DVAE_WORK(8.0 * (double)M * C, DVAE_UNIT_BYTE);                          // du and y, once each
-  DVAE_LAUNCH(colsum_kernel<0>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), du, y, scale, shift, mean,
-                     invstd, 0, ws, M, C, g.tx, g.ty);
+  DVAE_LAUNCH(colsum_kernel<0>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), (const float*)du, y, scale, shift,
+                     mean, invstd, 0, ws, M, C, g.tx, g.ty, (float*)nullptr);
   DVAE_LAUNCH_CHECK("bn_bwd_reduce");
   DVAE_LAUNCH(colsum_finalize_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), (const float*)ws, g.gx, 2, C,
                      dbeta, dgamma);
@@ -1319,8 +1319,8 @@ extern "C" int dvae_bn_bwd_reduce_f32(const float* du, const float* y, const flo
   DVAE_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd_reduce: need C%%4==0 (C=%ld)", (long)C);
   const ColsumGeom g = colsum_geom(M, C);
   DVAE_WORK(8.0 * (double)M * C, DVAE_UNIT_BYTE);                          // du and y, once each
-  DVAE_LAUNCH(colsum_kernel<0>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), const_cast<float*>(du), y,
-                     scale, shift, mean, invstd, 0, partials, M, C, g.tx, g.ty);
+  DVAE_LAUNCH(colsum_kernel<0>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), du, y,
+                     scale, shift, mean, invstd, 0, partials, M, C, g.tx, g.ty, (float*)nullptr);
   DVAE_LAUNCH_CHECK("bn_bwd_reduce");
   return 0;
 }
@@ -1343,12 +1343,13 @@ extern "C" int dvae_bn_bwd_from_partials_f32(float* du, const float* y, const fl
   return 0;
 }
 
-extern "C" int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, float* dbias, float* ws, int64_t M,
-                                     int64_t N, dvae_stream_t stream) {
+extern "C" int dvae_bias_act_bwd_to_f32(const float* dout, float* dpre, const float* out, int act, float* dbias,
+                                        float* ws, int64_t M, int64_t N, dvae_stream_t stream) {
   DVAE_REQUIRE(M > 0 && N > 0 && N % 4 == 0, "bias_act_bwd: need N%%4==0 (N=%ld)", (long)N);
   DVAE_REQUIRE(act == DVAE_ACT_NONE || act == DVAE_ACT_LRELU, "bias_act_bwd: unsupported activation %d", act);
-  if (act == DVAE_ACT_NONE && dbias == nullptr) return 0;
-  DVAE_WORK((act == DVAE_ACT_LRELU ? 12.0 : 4.0) * (double)M * N, DVAE_UNIT_BYTE);
+  DVAE_REQUIRE(dout && dpre, "bias_act_bwd: null gradient");
+  if (act == DVAE_ACT_NONE && dbias == nullptr && dpre == dout) return 0;
+  DVAE_WORK((act == DVAE_ACT_LRELU ? 12.0 : dpre != dout ? 8.0 : 4.0) * (double)M * N, DVAE_UNIT_BYTE);
   if (M <= 64) {
     // a handful of rows (latent heads at small batch): one launch; beyond that the two-stage form is faster.  Narrow column groups (at most 32 x 4 columns per workgroup) so that a workgroup
     // walks the rows with as many of them side by side as its 256 threads allow, and writes the sums itself.
@@ -1358,14 +1359,14 @@ extern "C" int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, flo
     const int ty = 256 / tx;
     DVAE_LAUNCH(colsum_kernel<1>, dim3(1, (unsigned)ceil_div64(c4, tx)), dim3(256), 0, ST(stream), dout, out,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act,
-                       dbias ? dbias : ws, M, N, tx, ty);
+                       dbias ? dbias : ws, M, N, tx, ty, dpre);
     DVAE_LAUNCH_CHECK("bias_act_bwd");
     return 0;
   }
   const ColsumGeom g = colsum_geom(M, N);
   DVAE_LAUNCH(colsum_kernel<1>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), dout, out,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, ws,
-                     M, N, g.tx, g.ty);
+                     M, N, g.tx, g.ty, dpre);
   DVAE_LAUNCH_CHECK("bias_act_bwd");
   if (dbias) {
     DVAE_LAUNCH(colsum_finalize_kernel, dim3((unsigned)N), dim3(256), 0, ST(stream), (const float*)ws, g.gx, 1,
@@ -1373,6 +1374,11 @@ extern "C" int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, flo
     DVAE_LAUNCH_CHECK("bias_act_bwd_finalize");
   }
   return 0;
+}
+
+extern "C" int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, float* dbias, float* ws, int64_t M,
+                                     int64_t N, dvae_stream_t stream) {
+  return dvae_bias_act_bwd_to_f32(dout, dout, out, act, dbias, ws, M, N, stream);
 }
 
 __global__ void __launch_bounds__(256)

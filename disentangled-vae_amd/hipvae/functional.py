@@ -213,8 +213,9 @@ class EncoderCNN(torch.autograd.Function):
         affs = ctx.affs
         F_out, C, S = ctx.fc_shape
         off = _OffPath(dfeat)
-        dpre = dfeat.contiguous().clone()
-        d_fc_b = ops.bias_act_bwd(dpre, feat, ops.ACT_LRELU, True)
+        dfeat = dfeat.contiguous()
+        dpre = torch.empty_like(dfeat)                           # the incoming gradient is not ours to overwrite
+        d_fc_b = ops.bias_act_bwd(dfeat, feat, ops.ACT_LRELU, True, dst=dpre)
         d_fc_w = off.run(lambda: ops.permute3(ops.gemm_tn(dpre, u_flat), (F_out, S, C), (0, 2, 1)).view(F_out, C * S),
                          dpre)                                   # via [F, S*C]
         du = ops.gemm_nn(dpre, w_perm).view(ys[-1].shape)        # grad wrt post-activation of last conv
@@ -450,8 +451,10 @@ class Linear(torch.autograd.Function):
         x2, w, out = ctx.saved_tensors
         d = dout.reshape(-1, w.shape[0]).contiguous()
         if ctx.act != ops.ACT_NONE:
-            d = d.clone()
-        db = ops.bias_act_bwd(d, out, ctx.act, ctx.has_bias)
+            d, d_in = torch.empty_like(d), d                     # the incoming gradient is not ours to overwrite
+            db = ops.bias_act_bwd(d_in, out, ctx.act, ctx.has_bias, dst=d)
+        else:
+            db = ops.bias_act_bwd(d, out, ctx.act, ctx.has_bias)
         off = _OffPath(d, ctx.needs_input_grad[0] and ctx.needs_input_grad[1])
         dw = off.run(lambda: ops.gemm_tn(d, x2), d) if ctx.needs_input_grad[1] else None
         dx = ops.gemm_nn(d, w.contiguous()).view(ctx.in_shape) if ctx.needs_input_grad[0] else None

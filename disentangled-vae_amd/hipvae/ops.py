@@ -328,14 +328,18 @@ def bn_bwd(du: Tensor, y: Tensor, scale, shift, mean, invstd, gamma, partials: O
     return dgb[0], dgb[1]
 
 
-def bias_act_bwd(dout: Tensor, out: Optional[Tensor], act: int, want_bias: bool) -> Optional[Tensor]:
-    """dout <- dout * act'(out) in place; returns column sums (bias gradient) if wanted."""
-    _chk(dout, out)
+def bias_act_bwd(dout: Tensor, out: Optional[Tensor], act: int, want_bias: bool,
+                 dst: Optional[Tensor] = None) -> Optional[Tensor]:
+    """dst <- dout * act'(out) (in place over dout when dst is None); returns column sums (bias gradient) if wanted."""
+    _chk(dout, out, dst)
     N = dout.shape[-1]
     M = dout.numel() // N
+    if dst is not None and dst.numel() != dout.numel():
+        raise RuntimeError("bias_act_bwd: dst must have dout's size")
     db = torch.empty(N, dtype=torch.float32, device=dout.device) if want_bias else None
     ws = workspace(lib.dvae_colsum_ws_floats(M, N), dout.device)
-    check(lib.dvae_bias_act_bwd_f32(_p(dout), _p(out), act, _p(db), _p(ws), M, N, _stream()), 'bias_act_bwd')
+    check(lib.dvae_bias_act_bwd_to_f32(_p(dout), _p(dout if dst is None else dst), _p(out), act, _p(db), _p(ws), M, N,
+                                       _stream()), 'bias_act_bwd')
     return db
 
 

@@ -202,6 +202,11 @@ int dvae_bn_bwd_from_partials_f32(float* du, const float* y, const float* scale,
  * dout (act NONE leaves it untouched), dbias[n] = sum_m dpre[m][n] (NULL to skip). [M,N], N%4==0. */
 int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, float* dbias, float* ws, int64_t M,
                           int64_t N, dvae_stream_t stream);
+/* The same with dpre written to its own [M,N] buffer and dout left untouched (autograd hands a node gradients it
+ * must not modify: torch's LeakyReLU/Linear backward, models/encoders.py:40-43, allocate their results too);
+ * dpre == dout is the in-place form above. */
+int dvae_bias_act_bwd_to_f32(const float* dout, float* dpre, const float* out, int act, float* dbias, float* ws,
+                             int64_t M, int64_t N, dvae_stream_t stream);
 /* dlogit = drecon * r * (1-r) (sigmoid backward), dbias[0] = sum(dlogit); n elements. */
 int dvae_sigmoid_bwd_f32(const float* drecon, const float* recon, float* dlogit, float* dbias, float* ws,
                          int64_t n, dvae_stream_t stream);

@@ -452,6 +452,12 @@ def test_bias_act_bwd(ops, M, N):
     d = dev(dout)
     db = ops.bias_act_bwd(d, None, ops.ACT_NONE, True)
     assert rel_err(d, dout) < 1e-7 and rel_err(db, dout.sum(0)) < 1e-5
+    # into a buffer of its own: the same values, the incoming gradient untouched
+    for act, want in ((ops.ACT_LRELU, ref), (ops.ACT_NONE, dout)):
+        d, dst = dev(dout), torch.full((M, N), float('nan'), device='cuda')
+        db = ops.bias_act_bwd(d, dev(out) if act == ops.ACT_LRELU else None, act, True, dst=dst)
+        assert torch.equal(d.cpu().double(), dout.float().double())
+        assert rel_err(dst, want) < 1e-7 and rel_err(db, want.sum(0)) < 1e-5
 
 
 def test_sigmoid_bwd(ops):
