@@ -280,6 +280,7 @@ def main():
     sync = GradSync(model, bucket_mb=args.bucket_mb) if (use_dp and not use_graph_early) else None
     ring = [synthetic_clips(B, T, size, 1000 * rank + i).to(dev) for i in range(4)]
     beta = 4.0
+    graph_fallback = []          # why the captured data-parallel step was given up, if it was
 
     def train_step(i):
         video = ring[i % len(ring)]
@@ -306,14 +307,38 @@ def main():
     use_graph = args.mode == 'train' and args.graph != 0
 
     def make_train_step():
+        nonlocal sync, use_graph
         model.train()
         if not use_graph:
             return train_step
         from hipvae.graph import GraphedDataParallelStep, GraphedTrainStep
         cls = GraphedDataParallelStep if use_dp else GraphedTrainStep
-        gstep = cls(model, opt, lambda m, v: loss_call(kind, L, m(v), v, t, beta), ring[0],
-                    gradient_clip=t['gradient_clip'])
-        return lambda i: gstep(ring[i % len(ring)])
+        loss_of = lambda m, v: loss_call(kind, L, m(v), v, t, beta)
+        if not use_dp:
+            gstep = cls(model, opt, loss_of, ring[0], gradient_clip=t['gradient_clip'])
+            return lambda i: gstep(ring[i % len(ring)])
+        # Several ranks: should capture fail on any rank (the collectives' own threads share the device with
+        # the capturing thread), every rank takes the eager data-parallel step instead - the same kernels,
+        # launched one by one, with the bucketed all-reduces overlapped with backward - and the result line says so.
+        gstep, why = None, ''
+        try:
+            if os.environ.get('DVAE_BENCH_FAIL_CAPTURE') == '1':         # rehearsal of the fallback below
+                raise RuntimeError('DVAE_BENCH_FAIL_CAPTURE=1')
+            gstep = cls(model, opt, loss_of, ring[0], gradient_clip=t['gradient_clip'])
+        except Exception as e:                                          # noqa: BLE001
+            why = f'{type(e).__name__}: {e}'
+            print(f'[bench] rank {rank}: captured data-parallel step failed ({why}); eager step instead',
+                  file=sys.stderr, flush=True)
+        ok = torch.tensor([0 if gstep is None else 1], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            return lambda i: gstep(ring[i % len(ring)])
+        del gstep
+        torch.cuda.synchronize()
+        use_graph = False
+        graph_fallback.append(why or 'capture failed on another rank')
+        sync = GradSync(model, bucket_mb=args.bucket_mb)
+        return train_step
 
     def barrier():
         if use_dp:
@@ -400,6 +425,8 @@ def main():
 
     if use_dp:
         result['rccl_world_size'] = dist.get_world_size()
+        if graph_fallback:
+            result['graph_fallback'] = graph_fallback[0][:300]
         result['config']['collective'] = ('two all-reduces (AVG) per step over RCCL on a side stream: decoder-side gradients while the encoders are still in backward, then the rest'
                                           if use_graph else 'bucketed all-reduces (AVG) over RCCL, overlapped with backward')
     gf = GFLOP_PER_CLIP.get(args.config)
