@@ -21,8 +21,8 @@ struct GemmArgs {
 };
 
 template <class T, int KIND, int BF>      // BF: PREC_F32 / PREC_BF16 / PREC_SPLIT
-__global__ void __launch_bounds__(256, 2) gemm_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * Core<T, BF>::STAGE];
+__global__ void __launch_bounds__(256, (DVAE_GEMM_ONE_STAGE && KIND == G_NT && BF == PREC_F32) ? 3 : 2) gemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[((DVAE_GEMM_ONE_STAGE && KIND == G_NT) ? 1 : 2) * Core<T, BF>::STAGE];
   const int64_t m0 = (int64_t)(blockIdx.y + g.tm0) * T::BM, n0 = (int64_t)blockIdx.x * T::BN;
   const int ktiles = (int)((g.K + 31) / 32);
   const int kt_begin = blockIdx.z * g.ktiles_per_split;

@@ -395,6 +395,10 @@ struct Core<T, PREC_BF16> {
 #ifndef DVAE_MMA_PRIO
 #define DVAE_MMA_PRIO 1
 #endif
+// experiment: the plain main loop on ONE LDS stage and two barriers per K step (three workgroups per CU)
+#ifndef DVAE_GEMM_ONE_STAGE
+#define DVAE_GEMM_ONE_STAGE 0
+#endif
 #if DVAE_MMA_PRIO
 #define MMA_PRIO_UP() __builtin_amdgcn_s_setprio(DVAE_MMA_PRIO)
 #define MMA_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
@@ -434,15 +438,23 @@ __device__ __forceinline__ void gemm_mainloop(LA& la, LB& lb, int kt_begin, int 
     MMA_PRIO_UP();
     C::mma(smem + cur * C::STAGE, acc, wm, wn, lane);
     MMA_PRIO_DOWN();
+#if DVAE_GEMM_ONE_STAGE
+    __syncthreads();          // one LDS stage: every wave has read it before it is overwritten
+    if (more) {
+      float* nx = smem;
+#else
     if (more) {
       float* nx = smem + (cur ^ 1) * C::STAGE;
+#endif
       la.finish(ra);
       lb.finish(rb);
       C::store_a(nx, ra);
       C::store_b(nx, rb);
     }
     __syncthreads();
+#if !DVAE_GEMM_ONE_STAGE
     cur ^= 1;
+#endif
   }
 }
 

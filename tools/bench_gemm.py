@@ -32,6 +32,8 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--precision', default='fp32')
     ap.add_argument('--layers', type=int, default=0, help='only the first N layer shapes (0: all)')
+    ap.add_argument('--pad', type=int, default=0, help='operands are views of buffers whose rows are this many floats '
+                    'longer (row strides that are not powers of two)')
     ap.add_argument('--error', action='store_true', help='also print the relative L2 error against an fp64 product')
     a = ap.parse_args()
     ops.set_precision(a.precision)
@@ -40,10 +42,12 @@ def main():
     layers = [(4864, 8192, 512), (5120, 640, 4096), (4864, 512, 1024), (4864, 256, 1024), (5120, 256, 512),
               (256, 4096, 512)]
     for M, K, N in (layers[:a.layers] if a.layers else layers):
-        x = torch.randn(M, K, device=dev)
-        w = torch.randn(N, K, device=dev) * 0.05
+        def rnd(r, c, scale=1.0):
+            return (torch.randn(r, c + a.pad, device=dev) * scale)[:, :c]
+        x = rnd(M, K)
+        w = rnd(N, K, 0.05)
         b = torch.randn(N, device=dev)
-        dy = torch.randn(M, N, device=dev)
+        dy = rnd(M, N)
         fl = 2.0 * M * N * K
         for name, fn in (('nt  y = x w^T + b ', lambda: ops.gemm_nt(x, w, b, ops.ACT_LRELU)),
                          ('nn  dx = dy w     ', lambda: ops.gemm_nn(dy, w)),
