@@ -18,7 +18,23 @@ struct GemmArgs {
   int64_t M, N, K;
   int act, accumulate, ktiles_per_split;
   int tm0;      // first row of tiles of this launch (a product may be split over two launches)
+  int wide_rows;  // rows of the output (and of the partial slabs) may be written 16 bytes at a time
 };
+
+// Diagnostic build only (-DDVAE_GEMM_STAMP=1, never the shipped library): every workgroup's shader-clock and
+// real-time ticks across its main loop, for the clock the chip holds under this load
+// (shader ticks / 100 MHz ticks x 100 MHz), read back with dvae_debug_read_stamps (tools/debug/clock_probe.py).
+#ifndef DVAE_GEMM_STAMP
+#define DVAE_GEMM_STAMP 0
+#endif
+#if DVAE_GEMM_STAMP
+#define STAMP_WGS 4096
+__device__ unsigned long long dvae_stamps[2 * STAMP_WGS];
+extern "C" int dvae_debug_read_stamps(unsigned long long* host, int n) {
+  if (n > 2 * STAMP_WGS) n = 2 * STAMP_WGS;
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dvae_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 template <class T, int KIND, int BF>      // BF: PREC_F32 / PREC_BF16 / PREC_SPLIT
 __global__ void __launch_bounds__(256, (DVAE_GEMM_ONE_STAGE && KIND == G_NT && BF == PREC_F32) ? 3 : 2) gemm_kernel(GemmArgs g) {
@@ -32,6 +48,9 @@ __global__ void __launch_bounds__(256, (DVAE_GEMM_ONE_STAGE && KIND == G_NT && B
   f32x16 acc[T::TM][T::TN];
   zero_acc<T>(acc);
 
+#if DVAE_GEMM_STAMP
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
   if (KIND == G_NT) {
     KCLoader<T::A_V4> la(g.A, g.lda, g.M, g.K, m0);
     KCLoader<T::B_V4> lb(g.B, g.ldb, g.N, g.K, n0);
@@ -48,8 +67,50 @@ __global__ void __launch_bounds__(256, (DVAE_GEMM_ONE_STAGE && KIND == G_NT && B
     else gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);
   }
 
-  if (g.slab) {
-    float* dst = g.slab + (int64_t)blockIdx.z * g.M * g.N;
+#if DVAE_GEMM_STAMP
+  {
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (threadIdx.x == 0 && id < STAMP_WGS) {
+      dvae_stamps[2 * id] = st1 - st0;
+      dvae_stamps[2 * id + 1] = sr1 - sr0;
+    }
+  }
+#endif
+  // Epilogue.  The accumulators hold four consecutive ROWS of one column per lane, so written straight from
+  // registers a tile leaves as 64 four-byte stores per lane; when every workgroup of a round reaches its epilogue at
+  // the same time (equal tiles) that store tail is not hidden by anybody's multiplies.  With whole, aligned rows the
+  // tile goes through the (now free) LDS stages instead and leaves as 16-byte stores along the rows: a quarter of
+  // the store instructions, 512 contiguous bytes per row and wave instruction.  Same values, same arithmetic.
+  constexpr int TLD = T::BN + 4;
+  constexpr bool fits = 2 * Core<T, BF>::STAGE >= T::BM * TLD;
+  float* dst = g.slab ? g.slab + (int64_t)blockIdx.z * g.M * g.N : g.C;
+  const int64_t ldd = g.slab ? g.N : g.ldc;
+  const bool wide = fits && g.wide_rows && m0 + T::BM <= g.M && n0 + T::BN <= g.N;
+  if (wide) {
+    for_each_acc<T>(acc, [&](int r, int c, float v) { smem[r * TLD + c] = v; });
+    __syncthreads();
+    constexpr int C4 = T::BN / 4, PER = T::BM * C4 / 256;
+    static_assert(256 % C4 == 0, "a thread keeps its columns for every piece it writes");
+    const int c4 = threadIdx.x % C4;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!g.slab && g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + n0 + 4 * c4);
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+      const int row = (it * 256 + threadIdx.x) / C4;
+      float4 o = *reinterpret_cast<const float4*>(smem + row * TLD + 4 * c4);
+      float4* p = reinterpret_cast<float4*>(dst + (m0 + row) * ldd + n0 + 4 * c4);
+      if (!g.slab) {
+        o.x += bias4.x; o.y += bias4.y; o.z += bias4.z; o.w += bias4.w;
+        if (g.act == DVAE_ACT_LRELU) { o.x = lrelu(o.x); o.y = lrelu(o.y); o.z = lrelu(o.z); o.w = lrelu(o.w); }
+        if (g.accumulate) {
+          const float4 q = *p;
+          o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+        }
+      }
+      *p = o;
+    }
+  } else if (g.slab) {
     for_each_acc<T>(acc, [&](int r, int c, float v) {
       const int64_t m = m0 + r, n = n0 + c;
       if (m < g.M && n < g.N) dst[m * g.N + n] = v;
@@ -280,6 +341,13 @@ static int launch_gemm(const char* name, GemmArgs g, float* ws, hipStream_t stre
       DVAE_LAUNCH((gemm_kernel<TILE, KIND_, PREC_F32>), GRID, dim3(256), 0, stream, g);           \
   }
   g.tm0 = 0;
+  {
+    static const bool narrow_only = [] { const char* v = getenv("DVAE_GEMM_NARROW_STORES"); return v && v[0] == '1'; }();
+    float* out = g.slab ? g.slab : g.C;
+    const int64_t ldo = g.slab ? g.N : g.ldc;
+    g.wide_rows = !narrow_only && ldo % 4 == 0 && aligned16(out) && (g.slab != nullptr || g.bias == nullptr || aligned16(g.bias)) &&
+                  (g.slab == nullptr || (g.M * g.N) % 4 == 0);
+  }
   // tiles that fill the 512 workgroup slots a whole number of times and then leave between a fifth and
   // seven tenths of a round: the remaining rows of tiles go to a second launch with 64-wide tiles,
   // which is a shorter last round than a mostly idle one

@@ -6,6 +6,7 @@ usage: python tools/bench_gemm.py [--reps 20] [--precision fp32|bf16|fp32_split]
 import argparse
 import os
 import sys
+import time
 
 import torch
 
@@ -14,9 +15,16 @@ sys.path.insert(0, os.path.join(ROOT, 'disentangled-vae_amd'))
 from hipvae import ops  # noqa: E402
 
 
-def timeit(fn, reps):
+def timeit(fn, reps, warm_s=0.3):
+    # the chip needs a few hundred milliseconds of load to settle its clock: timings taken right after a pause read
+    # up to 15 % slow (4864 x 8192 x 512 NT: 418 us after one warm-up launch, 361 us after two seconds of them)
     fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < warm_s:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
     s = torch.cuda.Event(enable_timing=True)
     e = torch.cuda.Event(enable_timing=True)
     s.record()
