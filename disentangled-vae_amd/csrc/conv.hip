@@ -17,6 +17,11 @@
 
 #define ST(s) ((hipStream_t)(s))
 #define CONV_MAX_PARTS 1024
+// timing-only build (-DDVAE_CONV_EPILOGUE_PROBE=1): the tiled forward kernels without their output stores and
+// without the loads of the BatchNorm-backward operand, i.e. what the epilogue's memory traffic costs
+#ifndef DVAE_CONV_EPILOGUE_PROBE
+#define DVAE_CONV_EPILOGUE_PROBE 0
+#endif
 
 static inline int ilog2(int64_t v) {
   int l = 0;
@@ -166,6 +171,7 @@ struct ConvArgs {
   const float* in_b;
   float* dx_out;
   int mt0;          // tiled kernels: first M tile of this launch (a layer may be split over two launches)
+  int part0;        // tiled kernels: first statistics partial row of this launch
   // tiled kernels, K split over gridDim.z (few M tiles: every workgroup takes kt_per K tiles and writes its partial
   // output, in output layout, to slab + blockIdx.z * slab_stride; conv_slab_reduce_kernel sums them); nullptr: no split
   float* slab;
@@ -375,7 +381,11 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
           const int64_t img = m >> (g.lw + g.lh);
           orow = (img * (2 * g.H) + (2 * a + ph)) * (2 * g.W) + (2 * b + pw);
         }
+#if DVAE_CONV_EPILOGUE_PROBE
+        if (v == 123.456f) yout[orow * g.Cout + n] = v;
+#else
         yout[orow * g.Cout + n] = v;
+#endif
       }
     });
     if (g.stats && !BNS && !split) {
@@ -412,7 +422,11 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
               orow = (img * (2 * g.H) + (2 * a + ph)) * (2 * g.W) + (2 * b + pw);
             }
             ok[r] = nok && m < g.M;
+#if DVAE_CONV_EPILOGUE_PROBE
+            yv[r] = ok[r] ? 0.5f : 0.f;
+#else
             yv[r] = ok[r] ? g.bn_y[orow * g.Cout + n] : 0.f;
+#endif
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -452,7 +466,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
       }
       const int64_t n = n0 + col;
       if (n < g.Cout) {
-        const int64_t part = (int64_t)phase * gx + bx;
+        const int64_t part = g.part0 + (int64_t)phase * gx + bx;
         g.stats[(part * 2 + 0) * g.Cout + n] = a;
         g.stats[(part * 2 + 1) * g.Cout + n] = b;
       }
@@ -1313,7 +1327,7 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
       g.mt0 = mt_begin;                                                                              \
       g.mtiles = mt_end;                                                                             \
     }                                                                                                \
-    int gx = g.mtiles - g.mt0 < CONV_MAX_PARTS ? g.mtiles - g.mt0 : CONV_MAX_PARTS;                  \
+    int gx = g.mtiles - g.mt0 < gx_cap ? g.mtiles - g.mt0 : gx_cap;                                  \
     dim3 grid(gx * phases, (unsigned)ceil_div64(g.Cout, TILE::BN), (unsigned)ksplit);                \
     {                                                                                                \
       int64_t rows_ = (int64_t)g.mtiles * TILE::BM;                                                  \
@@ -1335,6 +1349,7 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   }
   int mt_begin = 0, mt_end = -1;       // M-tile range of the next LAUNCH (-1: the whole layer)
   int ksplit = 1;                      // gridDim.z of the next LAUNCH
+  int gx_cap = CONV_MAX_PARTS;         // most workgroups along M (= statistics partial rows per phase) of the next LAUNCH
   typedef Tile<128, 128, 2, 2, true, true> T128;
   typedef Tile<128, 64, 4, 1, true, true> T64;
   typedef Tile<128, 32, 4, 1, true, true> T32;
@@ -1473,19 +1488,30 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     while (bn > 32 && row_tiles * ceil_div64(g.Cout, bn) < 256) bn >>= 1;
     // 128-wide tiles that fill the chip's 512 workgroup slots a whole number of times and then leave
     // between a fifth and seven tenths of a round: the remainder goes to a second launch with 64-wide
-    // tiles, which is a shorter last round than a mostly idle one.  (Not with statistics: the partial
-    // rows are numbered per launch.)
+    // tiles, which is a shorter last round than a mostly idle one.  With statistics the two launches share the
+    // layer's partial rows out in proportion to their M tiles: as many rows in all as one launch writes, the
+    // second launch's numbered after the first's.
     const int64_t tiles128 = row_tiles * ceil_div64(g.Cout, 128);
     const int64_t full = tiles128 / 512, rest = tiles128 % 512;
-    if (bn == 128 && g.stats == nullptr && full >= 1 && 5 * rest >= 512 && 10 * rest <= 7 * 512) {
+    static const bool split_stats = [] { const char* v = getenv("DVAE_CONV_SPLIT_STATS"); return !(v && v[0] == '0'); }();
+    if (bn == 128 && (g.stats == nullptr || (split_stats && !bns)) && full >= 1 && 5 * rest >= 512 && 10 * rest <= 7 * 512) {
       const int64_t per_mt = phases * ceil_div64(g.Cout, 128);          // workgroups per M tile
       const int split_mt = (int)(full * 512 / per_mt);
-      if (split_mt > 0 && split_mt < (int)ceil_div64(g.M, 128)) {
+      const int all_mt = (int)ceil_div64(g.M, 128);
+      const int64_t parts = conv_parts_written(g.M, phases) / phases;  // partial rows per phase of the whole layer
+      int gx1 = (int)(parts * split_mt / all_mt);
+      if (gx1 < 1) gx1 = 1;
+      const int gx2 = (int)parts - gx1;
+      if (split_mt > 0 && split_mt < all_mt && gx1 <= split_mt && gx2 >= 1 && gx2 <= all_mt - split_mt) {
         mt_begin = 0;
         mt_end = split_mt;
+        gx_cap = gx1;
+        g.part0 = 0;
         LAUNCH(T128, false)
         mt_begin = split_mt;
-        mt_end = (int)ceil_div64(g.M, 128);
+        mt_end = all_mt;
+        gx_cap = gx2;
+        g.part0 = gx1 * phases;
         LAUNCH(T64, false)
         DVAE_LAUNCH_CHECK(name);
         return 0;
@@ -1542,7 +1568,7 @@ static int conv4s2_fwd_impl(const char* name, const float* x, const float* in_sc
   g.cin32 = Cin % 32 == 0;
   g.bn_y = bn.y; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_invstd = bn.invstd;
   g.in_y = bi.y; g.in_a = bi.a; g.in_b = bi.b; g.dx_out = bi.dx_out;
-  g.slab = nullptr; g.slab_stride = 0; g.kt_per = 0; g.ws = ws; g.ws_floats = ws_floats;
+  g.slab = nullptr; g.slab_stride = 0; g.kt_per = 0; g.ws = ws; g.ws_floats = ws_floats; g.part0 = 0;
   DVAE_REQUIRE(bi.y == nullptr || (in_scale && in_shift && bi.a && bi.b && bi.dx_out && aligned16(bi.y) &&
                                    aligned16(bi.a) && aligned16(bi.b) && aligned16(bi.dx_out)),
                "%s: a BatchNorm-backward input needs y, scale, shift, A, B and dx_out, 16-byte aligned", name);
@@ -1569,7 +1595,7 @@ static int deconv4s2_fwd_impl(const char* name, const float* x, const float* in_
   g.cin32 = Cin % 32 == 0;
   g.bn_y = bn.y; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_invstd = bn.invstd;
   g.in_y = bi.y; g.in_a = bi.a; g.in_b = bi.b; g.dx_out = bi.dx_out;
-  g.slab = nullptr; g.slab_stride = 0; g.kt_per = 0; g.ws = ws; g.ws_floats = ws_floats;
+  g.slab = nullptr; g.slab_stride = 0; g.kt_per = 0; g.ws = ws; g.ws_floats = ws_floats; g.part0 = 0;
   DVAE_REQUIRE(bi.y == nullptr || (in_scale && in_shift && bi.a && bi.b && bi.dx_out && aligned16(bi.y) &&
                                    aligned16(bi.a) && aligned16(bi.b) && aligned16(bi.dx_out)),
                "%s: a BatchNorm-backward input needs y, scale, shift, A, B and dx_out, 16-byte aligned", name);

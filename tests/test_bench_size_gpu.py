@@ -68,7 +68,8 @@ CONV_BENCH = [
     (FRAMES, 16, 64, 128, True),    # 2560 row tiles with statistics: several M tiles per workgroup (> 1024 tiles)
     (FRAMES, 16, 64, 128, False),   # the same layer as a data gradient: 2560 tiles = 5 full rounds
     (FRAMES, 8, 128, 256, False),   # 1280 tiles of 128x128 = 2.5 rounds: 128-wide launch + 64-wide launch
-    (FRAMES, 8, 128, 256, True),    # with statistics: one launch
+    (FRAMES, 8, 128, 256, True),    # with statistics: the same two launches, sharing the partial rows out
+    (4864, 8, 128, 256, True),      # the motion encoder's frames: 1216 tiles = 2 rounds + 192 tiles for the 64-wide launch
     (4864, 32, 16, 32, True),       # motion encoder's second conv at 256 x 19 frames
 ]
 

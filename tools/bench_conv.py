@@ -4,6 +4,7 @@
 usage: python tools/bench_conv.py [--frames 5120] [--reps 10] [--only deconv|conv|wgrad]
 """
 import argparse
+import time
 import os
 import sys
 
@@ -14,9 +15,16 @@ sys.path.insert(0, os.path.join(ROOT, 'disentangled-vae_amd'))
 from hipvae import ops  # noqa: E402
 
 
-def timeit(fn, reps):
+def timeit(fn, reps, warm_s=0.2):
+    # launches for a fifth of a second first: right after a pause the chip's clock is still low and the first
+    # timings read up to 15 % slow
     fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < warm_s:
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
     s = torch.cuda.Event(enable_timing=True)
     e = torch.cuda.Event(enable_timing=True)
     s.record()
