@@ -38,7 +38,12 @@ extern "C" int dvae_debug_read_stamps(unsigned long long* host, int n) {
 
 template <class T, int KIND, int BF>      // BF: PREC_F32 / PREC_BF16 / PREC_SPLIT
 __global__ void __launch_bounds__(256, (DVAE_GEMM_ONE_STAGE && KIND == G_NT && BF == PREC_F32) ? 3 : 2) gemm_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float smem[((DVAE_GEMM_ONE_STAGE && KIND == G_NT) ? 1 : 2) * Core<T, BF>::STAGE];
+  // the K loop's stages, or the output tile on its way out (bf16 stages are smaller than the tile: 68 KB then,
+  // still two workgroups per CU)
+  constexpr int LOOP_FLOATS = ((DVAE_GEMM_ONE_STAGE && KIND == G_NT) ? 1 : 2) * Core<T, BF>::STAGE;
+  constexpr int TILE_FLOATS = T::BM * (T::BN + 4);
+  constexpr int SMEM_FLOATS = (BF == PREC_BF16 && TILE_FLOATS > LOOP_FLOATS) ? TILE_FLOATS : LOOP_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   const int64_t m0 = (int64_t)(blockIdx.y + g.tm0) * T::BM, n0 = (int64_t)blockIdx.x * T::BN;
   const int ktiles = (int)((g.K + 31) / 32);
   const int kt_begin = blockIdx.z * g.ktiles_per_split;
@@ -83,7 +88,7 @@ __global__ void __launch_bounds__(256, (DVAE_GEMM_ONE_STAGE && KIND == G_NT && B
   // tile goes through the (now free) LDS stages instead and leaves as 16-byte stores along the rows: a quarter of
   // the store instructions, 512 contiguous bytes per row and wave instruction.  Same values, same arithmetic.
   constexpr int TLD = T::BN + 4;
-  constexpr bool fits = 2 * Core<T, BF>::STAGE >= T::BM * TLD;
+  constexpr bool fits = SMEM_FLOATS >= T::BM * TLD;
   float* dst = g.slab ? g.slab + (int64_t)blockIdx.z * g.M * g.N : g.C;
   const int64_t ldd = g.slab ? g.N : g.ldc;
   const bool wide = fits && g.wide_rows && m0 + T::BM <= g.M && n0 + T::BN <= g.N;
