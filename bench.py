@@ -178,6 +178,86 @@ def hbm_floor(ms_per_step, bf16):
 
 
 # --------------------------------------------------------------------------------------------
+def synthetic_digit_bank(n=512, seed=1234):
+    """[n,28,28] float32 in [0,1]: blurred random strokes with MNIST's share of lit pixels (there is no MNIST on
+    the box and no network; the generator's cost does not depend on what the digits show)."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    bank = np.zeros((n, 28, 28), dtype=np.float32)
+    for i in range(n):
+        img = np.zeros((28, 28), dtype=np.float32)
+        p = rs.uniform(6, 22, size=2)
+        for _ in range(40):
+            p = np.clip(p + rs.uniform(-2.5, 2.5, size=2), 4, 24)
+            y, x = int(p[0]), int(p[1])
+            img[y - 1:y + 2, x - 1:x + 2] = np.maximum(img[y - 1:y + 2, x - 1:x + 2], rs.uniform(0.5, 1.0))
+        bank[i] = img
+    return (np.round(bank * 255) / 255).astype(np.float32)
+
+
+def trainer_epoch(config_name, batch, precision='fp32', train_size=10000, val_size=1000, epochs=2, use_graph=True,
+                  host_render=False):
+    """What `python -m training.train --config <json> --device cuda` delivers: Trainer.train_epoch() and
+    Trainer.validate() with the Trainer's defaults (steps and validation batches replayed from hipGraphs, clips
+    rendered on the GPU from host-simulated trajectories, losses accumulated on the device) over train_size /
+    val_size generated clips, beta = 4.  Epoch 0 pays for the captures; the last epoch is the rate reported.
+    Wall-clock around each call, device synchronised on both sides."""
+    import tempfile
+    from data import get_moving_mnist_dataloaders
+    from hipvae import ops
+    from training.config import ExperimentConfig
+    from training.trainer import create_trainer
+    ops.set_precision(precision)
+    cfg = ExperimentConfig.load(os.path.join(ROOT, 'disentangled-vae_amd', 'configs', config_name))
+    tmp = tempfile.mkdtemp(prefix='dvae_bench_')
+    cfg.data.train_size, cfg.data.val_size, cfg.data.test_size, cfg.data.batch_size = train_size, val_size, 8, batch
+    t = cfg.training
+    t.device, t.checkpoint_dir, t.results_dir = 'cuda', os.path.join(tmp, 'ck'), os.path.join(tmp, 'res')
+    t.beta_vae, t.use_kl_annealing, t.kl_start_epoch = 4.0, False, 0
+    if cfg.model.model_type == 'disentangled':
+        t.beta_content = t.beta_motion = 4.0
+    dev = torch.device('cuda', torch.cuda.current_device())
+    torch.manual_seed(0)
+    train_loader, val_loader, _ = get_moving_mnist_dataloaders(
+        digit_bank=synthetic_digit_bank(), batch_size=batch, train_size=train_size, val_size=val_size, test_size=8,
+        sequence_length=cfg.data.sequence_length, frame_size=cfg.data.frame_size, num_digits=cfg.data.num_digits,
+        num_workers=cfg.data.num_workers, seed=cfg.data.seed, pin_memory=host_render,
+        render_device=None if host_render else dev)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):                # the Trainer's own prints
+        tr = create_trainer(cfg, train_loader, val_loader)
+    tr.use_graph = use_graph
+    rows = []
+    for epoch in range(epochs):
+        tr.current_epoch = epoch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = tr.train_epoch()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        val = tr.validate()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        rows.append((t1 - t0, t2 - t1, out['total_loss'], val['total_loss']))
+    tr.wait_for_checkpoint()
+    if getattr(tr, 'writer', None) is not None:
+        tr.writer.close()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    ops.set_precision('fp32')
+    tt, tv, loss, vloss = rows[-1]
+    return {'batch': batch, 'train_clips': train_size, 'val_clips': val_size,
+            'train_epoch_s': round(tt, 4), 'train_clips_per_s': round(train_size / tt, 1),
+            'validate_s': round(tv, 4), 'validate_clips_per_s': round(val_size / tv, 1),
+            'first_epoch_train_s': round(rows[0][0], 4), 'first_epoch_validate_s': round(rows[0][1], 4),
+            'steps_per_epoch': len(train_loader), 'train_loss': round(loss, 3), 'val_loss': round(vloss, 3),
+            'graph_fallback': tr.graph_fallback_reason,
+            'path': ('hipGraph replay' if use_graph else 'eager launches') + ', ' +
+                    ('clips rendered by DataLoader workers, uploaded one batch ahead' if host_render
+                     else 'clips rendered on the GPU')}
+
+
 def cpu_baseline(kind, cfg, steps=10, warmup=3, batch=32):
     """The CPU oracle (oracle/vae_oracle.py, a restatement of the reference pinned to the reference's own
     vectors) timed on the host cores: training step = forward + loss + backward + clip + Adam; inference =
@@ -239,6 +319,9 @@ def main():
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group and use the data-parallel step even with one rank '
                          '(exercises the multi-GPU code path on a single GPU)')
+    ap.add_argument('--trainer', action='store_true',
+                    help='measure Trainer.train_epoch() + validate() (what the CLI runs: 10,000 / 1,000 generated clips) '
+                         'at batch 32 and at --batch instead of the device-resident ring, and print that as the line')
     ap.add_argument('--graph', type=int, default=-1, help='0: eager launches (several ranks: bucketed all-reduces '
                     'overlapped with backward); otherwise replay the captured step (several ranks: two hipGraphs '
                     'around one gradient all-reduce)')
@@ -267,6 +350,21 @@ def main():
 
     ops.set_precision(args.precision)
     cfg = load_config(args.config)
+    if args.trainer:
+        if world != 1:
+            raise SystemExit("--trainer measures the single-GPU command line")
+        rows = {f'batch{b}': trainer_epoch(args.config, b, args.precision, use_graph=args.graph != 0)
+                for b in sorted({32, args.batch})}
+        head = rows[f'batch{args.batch}']
+        print(json.dumps({
+            'metric': 'training clips/sec (20x64x64 Moving MNIST) through Trainer.train_epoch()', 'unit': 'clips/s',
+            'value': head['train_clips_per_s'], 'n_gpus': 1, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': PRECISION_LABEL[args.precision][0], 'data': 'synthetic',
+            'steps': head['steps_per_epoch'], 'warmup': head['steps_per_epoch'],
+            'ms_per_step': round(head['train_epoch_s'] / head['steps_per_epoch'] * 1e3, 3),
+            'config': {'workload': f"{cfg['name']} ({args.config}): one epoch of the Trainer, beta=4, {head['path']}"},
+            'trainer_epoch': rows}), flush=True)
+        return
     kind = cfg['model']['model_type']
     t = cfg['training']
     T, size = cfg['data']['sequence_length'], cfg['data']['frame_size']
@@ -512,6 +610,15 @@ def main():
                                     'whole_step_frac': round(gf2 * 32 / ms2 / PEAK_FP32_MFMA_TFLOPS, 4)}
                 del g2, m2, o2, r2
             result['batch32_configs'] = others
+            # the rate of the command-line path beside the ring numbers above: one epoch of the Trainer
+            try:
+                result['trainer_epoch'] = {f'batch{b}': trainer_epoch(args.config, b) for b in sorted({32, B})}
+                ring = {B: result['value'], 32: others['disentangled_simple.json']['value']}
+                for b in sorted({32, B}):
+                    result['trainer_epoch'][f'batch{b}']['vs_ring'] = round(
+                        result['trainer_epoch'][f'batch{b}']['train_clips_per_s'] / ring[b], 4)
+            except Exception as e:                                          # noqa: BLE001
+                result['trainer_epoch'] = {'error': f'{type(e).__name__}: {e}'[:300]}
     if use_dp:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == 'train':

@@ -523,11 +523,13 @@ kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, fl
   }
 }
 
-__global__ void kl_bwd_kernel(const float* mu, const float* logvar, const float* gscale, float coef, float* dmu,
-                              float* dlogvar, int64_t n, float free_bits) {
+__global__ void kl_bwd_kernel(const float* mu, const float* logvar, const float* gscale, float coef,
+                              const float* coef_dev, float inv_b, float* dmu, float* dlogvar, int64_t n,
+                              float free_bits) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const float c = coef * (gscale ? gscale[0] : 1.f);
+  // the weight of the term: a launch constant, or (coef_dev) a device scalar that may change between replays
+  const float c = ((coef_dev ? coef_dev[0] : coef) * inv_b) * (gscale ? gscale[0] : 1.f);
   const float m = mu[i], lv = logvar[i];
   const float e = expf(lv);
   float gm = c * m, gl = c * 0.5f * (e - 1.f);
@@ -550,12 +552,13 @@ extern "C" int dvae_kl_fwd_f32(const float* mu, const float* logvar, float* out,
   return 0;
 }
 
-extern "C" int dvae_kl_bwd_f32(const float* mu, const float* logvar, const float* gscale, float coef, float* dmu,
-                               float* dlogvar, int64_t B, int64_t D, float free_bits, dvae_stream_t stream) {
+extern "C" int dvae_kl_bwd_f32(const float* mu, const float* logvar, const float* gscale, float coef,
+                               const float* coef_dev, float* dmu, float* dlogvar, int64_t B, int64_t D,
+                               float free_bits, dvae_stream_t stream) {
   DVAE_REQUIRE(B > 0 && D > 0, "kl_bwd: empty");
   const int64_t n = B * D;
   DVAE_LAUNCH(kl_bwd_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ST(stream), mu, logvar,
-                     gscale, coef / (float)B, dmu, dlogvar, n, free_bits);
+                     gscale, coef, coef_dev, 1.f / (float)B, dmu, dlogvar, n, free_bits);
   DVAE_LAUNCH_CHECK("kl_bwd");
   return 0;
 }
@@ -573,6 +576,8 @@ struct LossFinishArgs {
   double B, T, P;
   const float* mu[2]; const float* lv[2]; int64_t D[2];
   float beta[2];
+  const float* beta_dev;     // device scalar that replaces beta[p] for the latents named in beta_dev_mask, or nullptr
+  int beta_dev_mask;
   int nkl;
   float free_bits, temporal_weight, indep_weight;
   const float* indep;        // value of the independence term (device scalar) or nullptr
@@ -633,18 +638,24 @@ __global__ void __launch_bounds__(1024) vae_loss_finish_kernel(LossFinishArgs a)
       kl_dim[p] = (float)(t[2 + 2 * p] / (a.B * (double)a.D[p]));
     }
     float total;
+    float beta[2] = {a.beta[0], a.beta[1]};
+    if (a.beta_dev) {
+      const float bd = a.beta_dev[0];
+      if (a.beta_dev_mask & 1) beta[0] = bd;
+      if (a.beta_dev_mask & 2) beta[1] = bd;
+    }
     if (a.layout == 0) {
       float s = 0.f;
       s += 1.f * rec;
-      s += a.beta[0] * kl_mean[0];
+      s += beta[0] * kl_mean[0];
       s += a.temporal_weight * tmp;
       total = s;
       a.out[0] = total; a.out[1] = per_pixel; a.out[2] = rec; a.out[3] = tmp;
       a.out[4] = kl_mean[0]; a.out[5] = kl_raw[0]; a.out[6] = kl_dim[0];
     } else {
       float kl = 0.f;
-      kl += a.beta[0] * kl_mean[0];
-      kl += a.beta[1] * kl_mean[1];
+      kl += beta[0] * kl_mean[0];
+      kl += beta[1] * kl_mean[1];
       const float ind = a.indep ? a.indep[0] : 0.f;
       float s = 0.f;
       s += 1.f * rec;
@@ -664,13 +675,15 @@ __global__ void __launch_bounds__(1024) vae_loss_finish_kernel(LossFinishArgs a)
 extern "C" int dvae_vae_loss_fwd_f32(const float* recon, const float* target, int64_t B, int64_t T, int64_t P, int kind,
                                      int with_temporal, const float* mu0, const float* logvar0, int64_t D0,
                                      float beta0, const float* mu1, const float* logvar1, int64_t D1, float beta1,
-                                     float free_bits, float temporal_weight, const float* indep, float indep_weight,
-                                     float* out, float* total_out, float* ws, dvae_stream_t stream) {
+                                     const float* beta_dev, int beta_dev_mask, float free_bits,
+                                     float temporal_weight, const float* indep, float indep_weight, float* out,
+                                     float* total_out, float* ws, dvae_stream_t stream) {
   DVAE_REQUIRE(B > 0 && T >= 1 && P > 0 && P % 4 == 0, "vae_loss_fwd: need P%%4==0");
   DVAE_REQUIRE(kind == 0 || kind == 1, "vae_loss_fwd: kind must be 0 (mse) or 1 (bce)");
   DVAE_REQUIRE(recon && target && mu0 && logvar0 && out && ws && D0 > 0, "vae_loss_fwd: null argument");
   DVAE_REQUIRE((mu1 == nullptr) == (logvar1 == nullptr) && (mu1 == nullptr || D1 > 0), "vae_loss_fwd: the second latent needs mu, logvar and its width");
   DVAE_REQUIRE(((uintptr_t)ws & 7) == 0, "vae_loss_fwd: workspace must be 8-byte aligned");
+  DVAE_REQUIRE((beta_dev_mask & ~3) == 0 && (beta_dev_mask == 0 || beta_dev), "vae_loss_fwd: beta_dev_mask names latents 0 and 1 and needs beta_dev");
   const int nb = recon_blocks(B, P);
   DVAE_WORK(8.0 * (double)B * T * P, DVAE_UNIT_BYTE);                      // recon and target, once each
   DVAE_LAUNCH(recon_loss_fwd_kernel, dim3(nb), dim3(256), 0, ST(stream), (const float4*)recon,
@@ -681,6 +694,7 @@ extern "C" int dvae_vae_loss_fwd_f32(const float* recon, const float* target, in
   a.B = (double)B; a.T = (double)T; a.P = (double)P;
   a.mu[0] = mu0; a.lv[0] = logvar0; a.D[0] = D0; a.beta[0] = beta0;
   a.mu[1] = mu1; a.lv[1] = logvar1; a.D[1] = mu1 ? D1 : 0; a.beta[1] = beta1;
+  a.beta_dev = beta_dev_mask ? beta_dev : nullptr; a.beta_dev_mask = beta_dev_mask;
   a.nkl = mu1 ? 2 : 1;
   a.free_bits = free_bits; a.temporal_weight = temporal_weight; a.indep_weight = indep_weight;
   a.indep = indep; a.layout = mu1 ? 1 : 0; a.out = out; a.total_out = total_out;
@@ -692,15 +706,19 @@ extern "C" int dvae_vae_loss_fwd_f32(const float* recon, const float* target, in
 // KL gradients of one or two latents in one launch (coef_i = beta_i; the 1/B of the batch mean is applied here)
 __global__ void kl_bwd2_kernel(const float* mu0, const float* lv0, float* dmu0, float* dlv0, int64_t n0, float c0,
                                const float* mu1, const float* lv1, float* dmu1, float* dlv1, int64_t n1, float c1,
-                               const float* gscale, float free_bits) {
+                               const float* coef_dev, int coef_dev_mask, float inv_b, const float* gscale,
+                               float free_bits) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const float* mu = mu0; const float* lvp = lv0; float* dmu = dmu0; float* dlv = dlv0; float coef = c0;
+  int which = 1;
   if (i >= n0) {
     i -= n0;
     if (i >= n1) return;
     mu = mu1; lvp = lv1; dmu = dmu1; dlv = dlv1; coef = c1;
+    which = 2;
   }
-  const float c = coef * (gscale ? gscale[0] : 1.f);
+  if (coef_dev_mask & which) coef = coef_dev[0];
+  const float c = (coef * inv_b) * (gscale ? gscale[0] : 1.f);
   const float m = mu[i], lv = lvp[i];
   const float e = expf(lv);
   float gm = c * m, gl = c * 0.5f * (e - 1.f);
@@ -717,14 +735,15 @@ __global__ void kl_bwd2_kernel(const float* mu0, const float* lv0, float* dmu0, 
 
 extern "C" int dvae_kl_bwd2_f32(const float* mu0, const float* logvar0, float coef0, float* dmu0, float* dlogvar0,
                                 int64_t D0, const float* mu1, const float* logvar1, float coef1, float* dmu1,
-                                float* dlogvar1, int64_t D1, const float* gscale, int64_t B, float free_bits,
-                                dvae_stream_t stream) {
+                                float* dlogvar1, int64_t D1, const float* coef_dev, int coef_dev_mask,
+                                const float* gscale, int64_t B, float free_bits, dvae_stream_t stream) {
   DVAE_REQUIRE(B > 0 && D0 > 0 && mu0 && logvar0 && dmu0 && dlogvar0, "kl_bwd2: empty or null");
   DVAE_REQUIRE(mu1 == nullptr || (logvar1 && dmu1 && dlogvar1 && D1 > 0), "kl_bwd2: the second latent is incomplete");
+  DVAE_REQUIRE((coef_dev_mask & ~3) == 0 && (coef_dev_mask == 0 || coef_dev), "kl_bwd2: coef_dev_mask names latents 0 and 1 and needs coef_dev");
   const int64_t n0 = B * D0, n1 = mu1 ? B * D1 : 0;
   DVAE_LAUNCH(kl_bwd2_kernel, dim3((unsigned)ceil_div64(n0 + n1, 256)), dim3(256), 0, ST(stream), mu0, logvar0, dmu0,
-                     dlogvar0, n0, coef0 / (float)B, mu1, logvar1, dmu1, dlogvar1, n1, coef1 / (float)B, gscale,
-                     free_bits);
+                     dlogvar0, n0, coef0, mu1, logvar1, dmu1, dlogvar1, n1, coef1, coef_dev, coef_dev_mask,
+                     1.f / (float)B, gscale, free_bits);
   DVAE_LAUNCH_CHECK("kl_bwd2");
   return 0;
 }

@@ -322,20 +322,31 @@ class DeviceClipLoader:
         if self.device.type != 'cuda':
             raise RuntimeError("DeviceClipLoader renders on the GPU; pass a cuda device")
         self._bank = None
+        self._stream = None
 
     def __len__(self) -> int:
         return len(self.batch_sampler)
 
     def render(self, indices):
-        """clips [len(indices),T,1,S,S] on the device and their metadata."""
+        """clips [len(indices),T,1,S,S] on the device and their metadata.  The uploads and the render kernel run
+        on a stream of this loader, so that the host never waits for the training stream (a copy from pageable
+        memory blocks the host until everything queued before it on ITS stream is done: on the training stream
+        that would be the whole step in flight); the caller's current stream is made to wait for the clips."""
         from hipvae import ops
         ds = self.dataset
         if self._bank is None:
             self._bank = torch.from_numpy(ds.digit_images).to(self.device).contiguous()
+            self._stream = torch.cuda.Stream(device=self.device)
+            torch.cuda.current_stream(self.device).synchronize()
         didx, ipos, metas = ds.simulate_batch(list(indices), self.with_meta)
-        didx = torch.from_numpy(didx).to(self.device, non_blocking=True)
-        pos = torch.from_numpy(ipos).to(self.device, non_blocking=True)
-        return ops.render_clips(self._bank, didx, pos, ds.frame_size), metas
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._stream):
+            didx = torch.from_numpy(didx).to(self.device, non_blocking=True)
+            pos = torch.from_numpy(ipos).to(self.device, non_blocking=True)
+            clips = ops.render_clips(self._bank, didx, pos, ds.frame_size)
+        cur.wait_stream(self._stream)
+        clips.record_stream(cur)            # allocated on the loader's stream, consumed on the caller's
+        return clips, metas
 
     def __iter__(self):
         # a DataLoader iterator draws its worker base seed from the global generator before its sampler

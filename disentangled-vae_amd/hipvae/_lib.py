@@ -47,9 +47,9 @@ SIGNATURES = {
     'dvae_render_clips_f32': (I, [P, L, P, P, P, L, L, L, L, L, P]),
     'dvae_set_mfma_precision': (I, [I]),
     'dvae_get_mfma_precision': (I, []),
-    'dvae_kl_bwd_f32': (I, [P, P, P, F, P, P, L, L, F, P]),
-    'dvae_vae_loss_fwd_f32': (I, [P, P, L, L, L, I, I, P, P, L, F, P, P, L, F, F, F, P, F, P, P, P, P]),
-    'dvae_kl_bwd2_f32': (I, [P, P, F, P, P, L, P, P, F, P, P, L, P, L, F, P]),
+    'dvae_kl_bwd_f32': (I, [P, P, P, F, P, P, P, L, L, F, P]),
+    'dvae_vae_loss_fwd_f32': (I, [P, P, L, L, L, I, I, P, P, L, F, P, P, L, F, P, I, F, F, P, F, P, P, P, P]),
+    'dvae_kl_bwd2_f32': (I, [P, P, F, P, P, L, P, P, F, P, P, L, P, I, P, L, F, P]),
     'dvae_indep_ws_floats': (L, [L, L]),
     'dvae_indep_fwd_f32': (I, [P, P, P, P, L, L, L, P]),
     'dvae_indep_bwd_f32': (I, [P, P, P, P, F, P, P, L, L, L, P]),

@@ -5,13 +5,18 @@ the batch-32 configurations are launch-bound without it).
 Captured through torch.cuda.graph (HIP graphs on ROCm): every kernel of libdvae_hip.so is launched on
 torch's current stream, so it is recorded like any torch op.  What changes from step to step lives in
 device memory: the input clip (a static buffer the batch is copied into), the Adam step count and
-learning rate (FusedAdam.enable_device_state) and the random draws (torch's graph-safe generator).
-Values baked into the graph: shapes, loss weights (beta included: re-capture when beta changes).
+learning rate (FusedAdam.enable_device_state), the KL weight when the loss is given a device scalar for it
+(losses.*_loss(beta_device=...)) and the random draws (torch's graph-safe generator; or, when a run injects
+prepared draws through hipvae.rng.inject_eps, static buffers that receive the next draws before each replay).
+Values baked into the graph: shapes and the other loss weights.
 """
+import contextlib
 from typing import Callable, Dict, Optional
 
 import torch
 import torch.distributed as dist
+
+from . import rng
 
 
 class GraphedTrainStep:
@@ -32,14 +37,25 @@ class GraphedTrainStep:
                     for p, st in optimizer.state.items()}
         dyn = optimizer.enable_device_state()
         dyn_snap = dyn.detach().clone()
+        # a run with injected normal draws: the captured step reads them from buffers of its own
+        inject = rng.injecting()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        rehearsed = None
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self._step()
+                with (rng.draw_slots() if inject else contextlib.nullcontext()) as rehearsed:
+                    self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self._capture()
+        # capture goes on the stream the warm-up ran on: the gradient-accumulation nodes that autograd made
+        # for the parameters during warm-up stay alive and keep that stream; recording the step on another one
+        # would put a cross-stream wait in front of every gradient (torch warns about exactly that)
+        self._capture_stream = side
+        # the draw buffers exist before capture begins (see rng.draw_slots), one per draw of the rehearsed step
+        self.eps_slots = [torch.zeros_like(b) for b in rehearsed] if inject else None
+        with (rng.draw_slots(self.eps_slots) if inject else contextlib.nullcontext()):
+            self._capture()
         # undo the warm-up steps
         with torch.no_grad():
             for t, s in zip(tensors, snap):
@@ -57,9 +73,19 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
 
     def _capture(self):
+        # thread-local capture mode: other threads of the process (a DataLoader's pinning thread, a checkpoint
+        # writer, a process group's watchdog) may call the runtime while this thread captures
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=self._capture_stream, capture_error_mode='thread_local'):
             self.losses = self._step()
+
+    def _before_replay(self, video: torch.Tensor):
+        self.static_video.copy_(video, non_blocking=True)
+        if self.eps_slots is not None:
+            rng.fill_slots(self.eps_slots)
+        elif rng.injecting():
+            raise RuntimeError("this step was captured without injected draws; capture it inside inject_eps()")
+        self.opt.sync_device_lr()
 
     def _step(self):
         self.opt.zero_grad(set_to_none=True)
@@ -73,8 +99,7 @@ class GraphedTrainStep:
     def __call__(self, video: torch.Tensor):
         """One training step on `video` (same shape as the example).  Returns the static LossDict whose
         device values are overwritten by every replay."""
-        self.static_video.copy_(video, non_blocking=True)
-        self.opt.sync_device_lr()
+        self._before_replay(video)
         self.graph.replay()
         self.opt.note_replayed_step()
         return self.losses
@@ -99,7 +124,7 @@ class GraphedForward:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local'), torch.no_grad():
             self.out = self.fn(model, self.static_in)
 
     def __call__(self, batch: torch.Tensor):
@@ -190,13 +215,14 @@ class GraphedDataParallelStep(GraphedTrainStep):
         # graphs share one memory pool and are always replayed in this order.
         torch.cuda.current_stream().wait_stream(self.staged.comm_stream)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+        cs = self._capture_stream
+        with torch.cuda.graph(self.graph, stream=cs, capture_error_mode='thread_local'):
             self.losses = self._stage1()
         self.graph_stage2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_stage2, pool=self.graph.pool(), capture_error_mode='thread_local'):
+        with torch.cuda.graph(self.graph_stage2, pool=self.graph.pool(), stream=cs, capture_error_mode='thread_local'):
             self.staged.stage2()
         self.graph_update = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_update, pool=self.graph.pool(), capture_error_mode='thread_local'):
+        with torch.cuda.graph(self.graph_update, pool=self.graph.pool(), stream=cs, capture_error_mode='thread_local'):
             # (finish() makes the capturing stream wait for the communication stream: outside capture)
             for p in self.staged.order:
                 p.grad = self.staged.views[id(p)]
@@ -205,8 +231,7 @@ class GraphedDataParallelStep(GraphedTrainStep):
             self.opt.step()
 
     def __call__(self, video: torch.Tensor):
-        self.static_video.copy_(video, non_blocking=True)
-        self.opt.sync_device_lr()
+        self._before_replay(video)
         self.graph.replay()
         self.staged.reduce(0)
         self.graph_stage2.replay()

@@ -195,44 +195,69 @@ def kl_fwd(mu, logvar, free_bits: float, out: Tensor):
     check(lib.dvae_kl_fwd_f32(_p(mu), _p(logvar), _p(out), B, D, float(free_bits), _stream()), 'kl_fwd')
 
 
-def kl_bwd(mu, logvar, gscale, coef: float, free_bits: float):
+def _dev_coef(latents, beta_dev):
+    """(plain coefficients, mask of the latents whose coefficient is the device scalar beta_dev): a latent whose
+    coefficient is given as None takes it from beta_dev."""
+    mask = 0
+    for p, l in enumerate(latents):
+        if l[2] is None:
+            if beta_dev is None:
+                raise RuntimeError("a latent without a coefficient needs beta_dev")
+            mask |= 1 << p
+    if mask:
+        _chk(beta_dev)
+        if beta_dev.numel() != 1:
+            raise RuntimeError("beta_dev must hold one float")
+    return [0.0 if l[2] is None else float(l[2]) for l in latents], mask
+
+
+def kl_bwd(mu, logvar, gscale, coef: Optional[float], free_bits: float, beta_dev: Optional[Tensor] = None):
+    """coef None: the coefficient is the device scalar beta_dev (read by the kernel at run time)"""
     _chk(mu, logvar, gscale)
     B, D = mu.shape
     dmu = torch.empty_like(mu)
     dlv = torch.empty_like(mu)
-    check(lib.dvae_kl_bwd_f32(_p(mu), _p(logvar), _p(gscale), float(coef), _p(dmu), _p(dlv), B, D,
-                              float(free_bits), _stream()), 'kl_bwd')
+    (c,), mask = _dev_coef([(mu, logvar, coef)], beta_dev)
+    check(lib.dvae_kl_bwd_f32(_p(mu), _p(logvar), _p(gscale), c, _p(beta_dev) if mask else None, _p(dmu), _p(dlv),
+                              B, D, float(free_bits), _stream()), 'kl_bwd')
     return dmu, dlv
 
 
 def vae_loss_fwd(recon, target, kind: int, with_temporal: bool, latents, free_bits: float, temporal_weight: float,
-                 indep: Optional[Tensor], indep_weight: float, out: Tensor, total_out: Optional[Tensor]):
+                 indep: Optional[Tensor], indep_weight: float, out: Tensor, total_out: Optional[Tensor],
+                 beta_dev: Optional[Tensor] = None):
     """The objective of one compute_loss call in two launches.  latents: [(mu, logvar, beta)] (one entry: 7 values
-    in `out`, two: 12; layouts in include/dvae_hip.h)."""
+    in `out`, two: 12; layouts in include/dvae_hip.h); beta None: that latent's weight is the device scalar
+    beta_dev."""
     _chk(recon, target, indep, out, total_out, *[t for l in latents for t in l[:2]])
     B, T = recon.shape[:2]
     P = recon[0, 0].numel()
     assert len(latents) in (1, 2) and all(mu.shape[0] == B and mu.shape == lv.shape for mu, lv, _ in latents)
     assert out.numel() >= (7 if len(latents) == 1 else 12)
     ws = workspace(lib.dvae_recon_loss_ws_floats(B, T, P), recon.device)
-    mu0, lv0, b0 = latents[0]
-    mu1, lv1, b1 = latents[1] if len(latents) == 2 else (None, None, 0.0)
+    coefs, mask = _dev_coef(latents, beta_dev)
+    mu0, lv0, _ = latents[0]
+    mu1, lv1, _ = latents[1] if len(latents) == 2 else (None, None, 0.0)
     check(lib.dvae_vae_loss_fwd_f32(_p(recon), _p(target), B, T, P, kind, int(with_temporal), _p(mu0), _p(lv0),
-                                    mu0.shape[1], float(b0), _p(mu1), _p(lv1), 0 if mu1 is None else mu1.shape[1],
-                                    float(b1), float(free_bits), float(temporal_weight), _p(indep),
+                                    mu0.shape[1], coefs[0], _p(mu1), _p(lv1), 0 if mu1 is None else mu1.shape[1],
+                                    coefs[1] if len(coefs) == 2 else 0.0, _p(beta_dev) if mask else None, mask,
+                                    float(free_bits), float(temporal_weight), _p(indep),
                                     float(indep_weight), _p(out), _p(total_out), _p(ws), _stream()), 'vae_loss_fwd')
 
 
-def kl_bwd2(latents, gscale, free_bits: float):
-    """[(mu, logvar, coef)] (one or two) -> [(dmu, dlogvar)] of coef * KL (batch mean) * gscale[0], one launch"""
+def kl_bwd2(latents, gscale, free_bits: float, beta_dev: Optional[Tensor] = None):
+    """[(mu, logvar, coef)] (one or two) -> [(dmu, dlogvar)] of coef * KL (batch mean) * gscale[0], one launch;
+    coef None: the device scalar beta_dev"""
     _chk(gscale, *[t for l in latents for t in l[:2]])
     B = latents[0][0].shape[0]
     outs = [(torch.empty_like(mu), torch.empty_like(mu)) for mu, _, _ in latents]
-    mu0, lv0, c0 = latents[0]
-    mu1, lv1, c1 = latents[1] if len(latents) == 2 else (None, None, 0.0)
+    coefs, mask = _dev_coef(latents, beta_dev)
+    mu0, lv0, _ = latents[0]
+    mu1, lv1, _ = latents[1] if len(latents) == 2 else (None, None, 0.0)
     o1 = outs[1] if len(latents) == 2 else (None, None)
-    check(lib.dvae_kl_bwd2_f32(_p(mu0), _p(lv0), float(c0), _p(outs[0][0]), _p(outs[0][1]), mu0.shape[1], _p(mu1),
-                               _p(lv1), float(c1), _p(o1[0]), _p(o1[1]), 0 if mu1 is None else mu1.shape[1],
+    check(lib.dvae_kl_bwd2_f32(_p(mu0), _p(lv0), coefs[0], _p(outs[0][0]), _p(outs[0][1]), mu0.shape[1], _p(mu1),
+                               _p(lv1), coefs[1] if len(coefs) == 2 else 0.0, _p(o1[0]), _p(o1[1]),
+                               0 if mu1 is None else mu1.shape[1], _p(beta_dev) if mask else None, mask,
                                _p(gscale), B, float(free_bits), _stream()), 'kl_bwd2')
     return outs
 

@@ -5,6 +5,10 @@ checkpoint layout, driving the MI355X kernels.
 What differs underneath:
   * forward, loss, backward, gradient norm/clip and Adam are HIP kernels (hipvae.*); there is no CPU
     path, so a configuration that does not resolve to a GPU is an error instead of a silent fallback;
+  * the training step (zero_grad ... Adam) is captured into a hipGraph per batch shape and replayed, and so is
+    the validation forward + loss; what changes between steps (the clip, Adam's step count and learning rate,
+    the annealed KL weight) is read from device memory.  Where a step cannot be captured the Trainer says why,
+    once, and issues the same kernels one by one (use_graph=False / DVAE_HIPGRAPH=0 selects that from the start);
   * loss values stay on the device during an epoch: one packed add per step, one read-back per
     logging interval / epoch, instead of >= 9 .item() synchronisations per step;
   * with torch.distributed initialised (one process per GPU) gradients are averaged across ranks by
@@ -126,8 +130,10 @@ class Trainer:
 
     def __init__(self, model: nn.Module, config: ExperimentConfig, train_loader, val_loader,
                  device: Optional[torch.device] = None, use_graph: Optional[bool] = None):
-        """use_graph: replay the training step as a captured hipGraph (with several ranks: two graphs around
-        one gradient all-reduce); default from the environment variable DVAE_HIPGRAPH (off unless '1')."""
+        """use_graph: replay the training step and the validation forward from captured hipGraphs (with several
+        ranks: three graphs with the gradient all-reduces between them); default True, the environment variable
+        DVAE_HIPGRAPH=0 turns it off.  A step that cannot be captured falls back to eager launches and the
+        reason is printed (see graph_fallback_reason)."""
         self.config = config
         self.train_loader = train_loader
         self.val_loader = val_loader
@@ -159,9 +165,16 @@ class Trainer:
             from hipvae.parallel import GradSync
             self.grad_sync = GradSync(self.model)
         if use_graph is None:
-            use_graph = os.environ.get('DVAE_HIPGRAPH', '0') == '1'
+            use_graph = os.environ.get('DVAE_HIPGRAPH', '1') != '0'
         self.use_graph = bool(use_graph)
-        self._graphs = {}                 # (batch shape, beta) -> GraphedTrainStep
+        self._graphs = {}                 # batch shape -> GraphedTrainStep
+        self._val_graphs = {}             # batch shape -> GraphedForward of the validation forward + loss
+        self.graph_fallback_reason = None  # why a step ran eagerly although use_graph is set (last reason)
+        self._fallback_said = set()
+        # the KL weight of the current epoch as a device scalar: the captured loss kernels read it, so one
+        # capture per batch shape serves every value of the annealing schedule
+        self._beta_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._beta_host = 0.0
         self.async_checkpoint = os.environ.get('DVAE_ASYNC_CKPT', '1') != '0'
         self._ckpt_thread, self._ckpt_stream, self._ckpt_keep, self._ckpt_error = None, None, None, None
 
@@ -198,25 +211,52 @@ class Trainer:
     def _get_beta(self, epoch: int) -> float:
         return beta_for_epoch(self.config.training, epoch)
 
-    def _compute_loss(self, video: torch.Tensor, beta: float) -> Tuple[Dict[str, torch.Tensor], torch.Tensor]:
+    def _compute_loss(self, video: torch.Tensor, beta: float, beta_device: Optional[torch.Tensor] = None
+                      ) -> Tuple[Dict[str, torch.Tensor], torch.Tensor]:
+        """beta_device: the device scalar holding beta, for a step that is being captured (the kernels then read
+        beta when they run instead of taking it as a launch constant)."""
         t = self.config.training
+        dyn = {} if beta_device is None else {'beta_device': beta_device}
         if self.model_type == 'disentangled_vae':
             output = self.model(video)
             losses = self.loss_fn(output, video, beta=beta, beta_content=t.beta_content, beta_motion=t.beta_motion,
                                   recon_loss_type=t.recon_loss_type, temporal_weight=t.temporal_weight,
-                                  independence_weight=t.independence_weight)
+                                  independence_weight=t.independence_weight, **dyn)
             return losses, output['recon']
         recon, z, mu, logvar = self.model(video)
         # temporal_weight is not forwarded on this path (the reference does not either, :171-177)
         losses = self.loss_fn(recon, video, mu, logvar, beta=beta, recon_loss_type=t.recon_loss_type,
-                              free_bits=t.free_bits, use_free_bits=t.use_free_bits)
+                              free_bits=t.free_bits, use_free_bits=t.use_free_bits, **dyn)
         return losses, recon
+
+    def _set_device_beta(self, beta: float):
+        if float(beta) != self._beta_host:
+            self._beta_dev.fill_(float(beta))
+            self._beta_host = float(beta)
+
+    def _capturable(self) -> Optional[str]:
+        """None when a step may be captured now, else the reason why not."""
+        if self.loss_fn not in (baseline_loss, lstm_loss, disentangled_loss):
+            return "a user-supplied loss function may hold beta as a launch constant"
+        return None
+
+    def _fall_back(self, what: str, why: str):
+        self.graph_fallback_reason = why
+        if (what, why) not in self._fallback_said:
+            self._fallback_said.add((what, why))
+            if self.rank == 0:
+                print(f"[trainer] {what} runs as eager launches, not as a hipGraph replay: {why}", flush=True)
 
     # ------------------------------------------------------------------ one optimisation step
     def train_step(self, video: torch.Tensor, beta: float):
         """zero_grad, forward, loss, backward, (all-reduce), clip, Adam (training/trainer.py:192-204)."""
         if self.use_graph:
-            return self._graphed_step(video, beta)
+            losses = self._graphed_step(video, beta)
+            if losses is not None:
+                return losses
+        if self.grad_sync is None and self.distributed:
+            from hipvae.parallel import GradSync            # the captured step had taken the hooks away
+            self.grad_sync = GradSync(self.model)
         if self.grad_sync is not None:
             self.grad_sync.zero_grad()
         else:
@@ -232,33 +272,47 @@ class Trainer:
         return losses
 
     def _graphed_step(self, video: torch.Tensor, beta: float):
-        """The same step replayed from a hipGraph captured for this batch shape and beta; beta is a
-        constant of the captured graph, so each annealing value gets its own capture (one per epoch
-        during warm-up) and only the newest two are kept."""
+        """The same step replayed from a hipGraph captured for this batch shape (the full and the ragged last
+        batch get one each).  Beta is read from device memory by the captured kernels.  Returns None when the
+        step cannot be captured (the caller then runs it eagerly)."""
         from hipvae.graph import GraphedDataParallelStep, GraphedTrainStep
-        key = (tuple(video.shape), float(beta))
+        why = self._capturable()
+        if why is not None:
+            self._fall_back('the training step', why)
+            return None
+        self._set_device_beta(beta)
+        from hipvae import rng
+        key = tuple(video.shape) + (rng.injecting(),)          # a run with injected draws captures its own form
         g = self._graphs.get(key)
-        if g is not None:
-            self._graphs[key] = self._graphs.pop(key)          # most recently used last
-        else:
-            # room for the full and the ragged last batch of the current and the previous beta
-            while len(self._graphs) >= 4:
+        if g is False:                                         # capture failed for this shape before
+            return None
+        if g is None:
+            while len(self._graphs) >= 4:                      # oldest first; two shapes per epoch in practice
                 self._graphs.pop(next(iter(self._graphs)))
-            loss_of = lambda m, v: self._compute_loss(v, beta)[0]
+            loss_of = lambda m, v: self._compute_loss(v, beta, self._beta_dev)[0]
             clip = self.config.training.gradient_clip
-            if self.distributed:
-                # several ranks: two graphs around one all-reduce of the flat gradient buffer.  The hooks
-                # of the eager path must not fire under capture; the parameters were broadcast when the
-                # Trainer was built and every rank has taken the same steps since.
-                if self.grad_sync is not None:
-                    self.grad_sync.remove()
-                    self.grad_sync = None
-                g = GraphedDataParallelStep(self.model, self.optimizer, loss_of, video, gradient_clip=clip,
-                                            broadcast_parameters=False)
-            else:
-                g = GraphedTrainStep(self.model, self.optimizer, loss_of, video, gradient_clip=clip)
+            try:
+                if self.distributed:
+                    # several ranks: graphs around the all-reduces of the flat gradient buffer.  The hooks of
+                    # the eager path must not fire under capture; the parameters were broadcast when the
+                    # Trainer was built and every rank has taken the same steps since.
+                    if self.grad_sync is not None:
+                        self.grad_sync.remove()
+                        self.grad_sync = None
+                    g = GraphedDataParallelStep(self.model, self.optimizer, loss_of, video, gradient_clip=clip,
+                                                broadcast_parameters=False)
+                else:
+                    g = GraphedTrainStep(self.model, self.optimizer, loss_of, video, gradient_clip=clip)
+            except Exception as e:                              # noqa: BLE001
+                if self.distributed:
+                    raise           # ranks that disagree about the path would hang in each other's collectives
+                self._graphs[key] = False
+                self._fall_back('the training step', f'capture failed ({type(e).__name__}: {e})')
+                return None
             self._graphs[key] = g
-        return g(video)
+        losses = g(video)
+        losses['beta'] = torch.tensor(beta)                     # the static dictionary reports this step's beta
+        return losses
 
     @staticmethod
     def _unpack(losses, packed_cpu) -> Dict[str, float]:
@@ -325,14 +379,40 @@ class Trainer:
         beta = self.config.training.beta_vae          # the final beta, not the annealed one (reference :243)
         acc, last, n = None, None, 0
         for video, _meta in DevicePrefetcher(self.val_loader, self.device):
-            last, _ = self._compute_loss(video, beta)
+            last = self._validation_losses(video, beta)
             acc = last.packed.clone() if acc is None else acc.add_(last.packed)
             n += 1
         if n == 0:
             return {}
+        hip_ops.check_lstm_seq_timeouts()      # (the read-back below synchronises anyway)
         out = self._unpack(last, self._rank_mean(acc / n).cpu())
         out['beta'] = beta
         return out
+
+    def _validation_losses(self, video: torch.Tensor, beta: float):
+        """Forward + loss of one validation batch (eval mode, no gradients): replayed from a hipGraph per batch
+        shape, or launched eagerly when capture is off or not possible."""
+        why = self._capturable() if self.use_graph else 'off'
+        if why is None:
+            key = tuple(video.shape)
+            g = self._val_graphs.get(key)
+            if g is None:
+                from hipvae.graph import GraphedForward
+                self._set_device_beta(beta)
+                try:
+                    g = GraphedForward(self.model, video, lambda m, v: self._compute_loss(v, beta, self._beta_dev)[0])
+                except Exception as e:                          # noqa: BLE001
+                    g = False
+                    self._fall_back('validation', f'capture failed ({type(e).__name__}: {e})')
+                while len(self._val_graphs) >= 4:
+                    self._val_graphs.pop(next(iter(self._val_graphs)))
+                self._val_graphs[key] = g
+            if g is not False:
+                self._set_device_beta(beta)
+                return g(video)
+        elif self.use_graph:
+            self._fall_back('validation', why)
+        return self._compute_loss(video, beta)[0]
 
     # ------------------------------------------------------------------ checkpoints
     def save_checkpoint(self, filename: str = 'checkpoint.pt'):
@@ -427,6 +507,7 @@ class Trainer:
         # the next step (parameters and Adam moments keep their storage, but a capture also bakes in
         # anything the optimiser created lazily at its first step)
         self._graphs.clear()
+        self._val_graphs.clear()
         self.current_epoch = ckpt['epoch']            # resumes AT the saved epoch, as the reference does
         self.global_step = ckpt['global_step']
         self.best_val_loss = ckpt['best_val_loss']

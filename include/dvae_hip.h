@@ -119,9 +119,11 @@ int dvae_reparam_bwd_f32(const float* dz, const float* logvar, const float* eps,
  *      out[1] = the same without the floor, out[2] = mean over all B*D of the floored values. */
 int dvae_kl_fwd_f32(const float* mu, const float* logvar, float* out, int64_t B, int64_t D,
                     float free_bits, dvae_stream_t stream);
-/* dmu, dlogvar of coef * (*gscale) * out[0]. */
-int dvae_kl_bwd_f32(const float* mu, const float* logvar, const float* gscale, float coef, float* dmu,
-                    float* dlogvar, int64_t B, int64_t D, float free_bits, dvae_stream_t stream);
+/* dmu, dlogvar of coef * (*gscale) * out[0].  coef_dev (optional): a device scalar read by the kernel in place of
+ *      coef -- the annealed beta of training/trainer.py:115-149 changes per epoch, and a step captured into a
+ *      hipGraph must not hold it as a launch constant. */
+int dvae_kl_bwd_f32(const float* mu, const float* logvar, const float* gscale, float coef, const float* coef_dev,
+                    float* dmu, float* dlogvar, int64_t B, int64_t D, float free_bits, dvae_stream_t stream);
 
 /* ---- the whole objective of one compute_loss call (models/disentangled_vae.py:222-292, models/lstm_vae.py:167-220,
  *      models/baseline_vae.py:208-252) in two launches: the pass over the clips, then one workgroup that sums its
@@ -130,16 +132,21 @@ int dvae_kl_bwd_f32(const float* mu, const float* logvar, const float* gscale, f
  *      recon, temporal, kl (free-bits floor applied), kl raw, kl per dim.
  *      Two latents, out[12]: total = recon + kl + temporal_weight*temporal + indep_weight*indep, kl = beta0*kl0 +
  *      beta1*kl1, recon per pixel, recon, temporal, kl0 (mean, raw, per dim), kl1 (same), indep (*indep, or 0).
- *      total_out (optional): the total once more.  ws: dvae_recon_loss_ws_floats() floats, 8-byte aligned. */
+ *      total_out (optional): the total once more.  ws: dvae_recon_loss_ws_floats() floats, 8-byte aligned.
+ *      beta_dev / beta_dev_mask: bit p set = latent p's weight is the device scalar *beta_dev instead of beta_p
+ *      (the per-epoch annealed beta of training/trainer.py:185 that `beta_c = beta_content if beta_content is not
+ *      None else beta`, models/disentangled_vae.py:243-244, falls back to); mask 0 = both are launch constants. */
 int dvae_vae_loss_fwd_f32(const float* recon, const float* target, int64_t B, int64_t T, int64_t P, int kind,
                           int with_temporal, const float* mu0, const float* logvar0, int64_t D0, float beta0,
-                          const float* mu1, const float* logvar1, int64_t D1, float beta1, float free_bits,
-                          float temporal_weight, const float* indep, float indep_weight, float* out,
-                          float* total_out, float* ws, dvae_stream_t stream);
-/* gradients of coef_i * KL_i (batch mean) wrt mu_i, logvar_i for one or two latents in one launch, times gscale[0] */
+                          const float* mu1, const float* logvar1, int64_t D1, float beta1, const float* beta_dev,
+                          int beta_dev_mask, float free_bits, float temporal_weight, const float* indep,
+                          float indep_weight, float* out, float* total_out, float* ws, dvae_stream_t stream);
+/* gradients of coef_i * KL_i (batch mean) wrt mu_i, logvar_i for one or two latents in one launch, times gscale[0];
+ *      coef_dev / coef_dev_mask as beta_dev / beta_dev_mask above */
 int dvae_kl_bwd2_f32(const float* mu0, const float* logvar0, float coef0, float* dmu0, float* dlogvar0, int64_t D0,
                      const float* mu1, const float* logvar1, float coef1, float* dmu1, float* dlogvar1, int64_t D1,
-                     const float* gscale, int64_t B, float free_bits, dvae_stream_t stream);
+                     const float* coef_dev, int coef_dev_mask, const float* gscale, int64_t B, float free_bits,
+                     dvae_stream_t stream);
 
 /* ---- independence term (models/disentangled_vae.py:270-278): mean of the squared cross-correlation
  *      of the standardised latents (unbiased std + 1e-8, correlation / B).

@@ -846,6 +846,29 @@ def test_vae_loss_in_two_launches(ops, kind, tw, free_bits):
     r0 = ops.kl_bwd(dev(mu0), dev(lv0), gs, 0.4, free_bits)
     r1 = ops.kl_bwd(dev(mu1), dev(lv1), gs, 4.0, free_bits)
     assert torch.equal(a0, r0[0]) and torch.equal(b0, r0[1]) and torch.equal(a1, r1[0]) and torch.equal(b1, r1[1])
+    # the KL weight read from a device scalar (what a captured step uses while beta is annealed): same bits as
+    # the launch constant, for either latent alone and for both, and it follows the scalar between launches
+    bd = torch.tensor([4.0], device='cuda')
+    for lat, dyn in (([(dev(mu0), dev(lv0), 0.4), (dev(mu1), dev(lv1), None)], bd),
+                     ([(dev(mu0), dev(lv0), None), (dev(mu1), dev(lv1), None)], torch.tensor([0.4], device='cuda'))):
+        out2, total2 = torch.full((12,), -1.0, device='cuda'), torch.full((1,), -1.0, device='cuda')
+        ops.vae_loss_fwd(dev(recon), dev(target), knd, tw > 0, lat, 0.0, tw, ind, 0.02, out2, total2, dyn)
+        if lat[0][2] is not None:
+            assert torch.equal(out2, out) and torch.equal(total2, total)
+            (c0, d0), (c1, d1) = ops.kl_bwd2(lat, gs, free_bits, dyn)
+            assert torch.equal(c0, a0) and torch.equal(d0, b0) and torch.equal(c1, a1) and torch.equal(d1, b1)
+        else:
+            k01 = 0.4 * k0 + 0.4 * k1
+            assert abs(out2[1].item() - float(k01)) <= 2e-6 * abs(float(k01))
+            (c0, d0), (c1, d1) = ops.kl_bwd2(lat, gs, free_bits, dyn)
+            r1b = ops.kl_bwd(dev(mu1), dev(lv1), gs, 0.4, free_bits)
+            assert torch.equal(c0, a0) and torch.equal(c1, r1b[0]) and torch.equal(d1, r1b[1])
+    bd.fill_(0.4)
+    r1c = ops.kl_bwd(dev(mu1), dev(lv1), gs, None, free_bits, bd)
+    r1d = ops.kl_bwd(dev(mu1), dev(lv1), gs, 0.4, free_bits)
+    assert torch.equal(r1c[0], r1d[0]) and torch.equal(r1c[1], r1d[1])
+    with pytest.raises(RuntimeError):
+        ops.kl_bwd(dev(mu1), dev(lv1), gs, None, free_bits)
 
 
 # ------------------------------------------------------------------ optimiser

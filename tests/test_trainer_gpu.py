@@ -44,6 +44,11 @@ def test_trainer_run_matches_reference(tmp_path):
     eps = [torch.from_numpy(arrays[f'eps{k}']) for k in range(9)]
     with rng.inject_eps(eps):
         hist = tr.train()
+    # default flags: every training step and every validation batch was a hipGraph replay (the injected draws
+    # travel through the captured step's draw buffers), one capture for all three values of the annealed beta
+    assert tr.use_graph and tr.graph_fallback_reason is None
+    assert len(tr._graphs) == 1 and len(tr._val_graphs) == 1 and all(tr._graphs.values())
+    assert next(iter(tr._graphs.values())).eps_slots is not None
     ref = info['history']
     assert sorted(hist) == sorted(ref)
     for k in ref:
@@ -181,8 +186,8 @@ def test_graphed_step_equals_eager_steps():
 
 
 def test_trainer_with_graph_replay_matches_eager(tmp_path):
-    """Trainer(use_graph=True): three epochs with KL annealing (beta changes per epoch, so the step is
-    re-captured mid-training) give the history of the eager Trainer.  Normal draws are zero in both runs
+    """Trainer(use_graph=True): three epochs with KL annealing (beta changes per epoch and reaches the one
+    captured step through device memory) give the history of the eager Trainer.  Normal draws are zero in both runs
     (a captured graph draws from torch's generator, an eager run from the same generator at different
     offsets, so equal noise needs a fixed value)."""
     from hipvae import rng
@@ -208,8 +213,10 @@ def test_trainer_with_graph_replay_matches_eager(tmp_path):
             tr.use_graph = use_graph
             hists.append(tr.train())
             if use_graph:
-                betas = {k[1] for k in tr._graphs}
-                assert len(tr._graphs) <= 4 and len(betas) >= 1
+                assert len(tr._graphs) == 1 and len(tr._val_graphs) == 1     # one capture serves every beta
+                assert tr.graph_fallback_reason is None
+            else:
+                assert not tr._graphs and not tr._val_graphs
                 sd = tr.optimizer.state_dict()
                 assert float(sd['state'][0]['step']) == 9.0          # 3 epochs x 3 batches, warm-ups undone
     finally:
@@ -448,11 +455,29 @@ def test_gradsync_on_rccl_single_rank_equals_plain_step():
         assert torch.equal(graphed[k], graphed_dp[k]), (k, (graphed[k].float() - graphed_dp[k].float()).abs().max().item())
 
 
-@pytest.mark.parametrize('flags', [[], ['--hip-graph', '--gpu-render'], ['--precision', 'bf16', '--gpu-render']])
+def test_trainer_says_why_a_step_is_not_replayed(tmp_path, capsys):
+    """A loss function the Trainer does not know may hold beta as a launch constant: the step then runs as eager
+    launches and the reason is printed once and kept."""
+    from hipvae import losses
+    from training.trainer import create_trainer
+    cfg = _tiny_trainer_config(tmp_path, 'why', 1)
+    train = [(synthetic_clips(4, 6, 20 + i), [{}] * 4) for i in range(2)]
+    torch.manual_seed(5)
+    tr = create_trainer(cfg, train, train[:1])
+    assert tr.use_graph                                          # the default
+    tr.loss_fn = lambda *a, **k: losses.baseline_loss(*a, **k)
+    out = tr.train_epoch()
+    assert np.isfinite(out['total_loss']) and not tr._graphs
+    assert 'user-supplied loss' in tr.graph_fallback_reason
+    assert capsys.readouterr().out.count('runs as eager launches') == 1
+
+
+@pytest.mark.parametrize('flags', [[], ['--no-hip-graph', '--host-render'], ['--precision', 'bf16']])
 def test_cli_end_to_end(tmp_path, flags):
     """`python -m training.train --config <json> --device cuda` (here: its main() in process) on a tiny
     configuration with digit images from a file: two epochs, checkpoints and history written, losses
-    finite and decreasing; the same with the graph-replayed step + GPU-rendered clips, and in bf16 mode."""
+    finite and decreasing.  Default flags = graph-replayed step and validation + GPU-rendered clips; then the
+    host-driven forms (eager launches, clips rendered by the DataLoader), and bf16 mode."""
     import hipvae
     from tests.golden.make_golden import synthetic_digit_bank
     from training import train as train_cli
