@@ -318,6 +318,11 @@ static double* scratch_on_current_device() {
 
 extern "C" int64_t dvae_recon_metrics_noalloc_max_elements(void) { return DVAE_NOALLOC_MAX_ELEMENTS; }
 
+// Looks the scratch array's address up on the current device now, so that the first dvae_recon_metrics_noalloc_f32
+// on this device makes no runtime call besides its two launches (a symbol look-up may load the code object, which a
+// stream under graph capture does not allow).
+extern "C" int dvae_recon_metrics_noalloc_init(void) { return scratch_on_current_device() ? 0 : -EIO; }
+
 extern "C" int dvae_recon_metrics_noalloc_f32(const float* recon, const float* target, float* out, int64_t B,
                                               int64_t T, int64_t P, float max_val, dvae_stream_t stream) {
   DVAE_REQUIRE(B > 0 && T >= 1 && P > 0 && P % 4 == 0, "recon_metrics_noalloc: need P%%4==0 (P=%ld)", (long)P);

@@ -13,6 +13,8 @@
 // no grid-wide barrier -- only the H/8 workgroups that serve one group of 32 batch rows hand data to each
 // other, through 16-byte write-through stores, one arrival counter per group and L1-bypassing loads.
 #include "common.h"
+#include <mutex>
+#include <cstdlib>
 #include "../../include/dvae_hip.h"
 
 #define ST(s) ((hipStream_t)(s))
@@ -416,8 +418,10 @@ extern "C" int dvae_skinny_gemm_nt_f32(const float* a, int64_t ld_a, const float
 // written step t, i.e. has finished reading step t-1.  Groups never wait for each other.  Workgroups of a
 // group are numbered eight apart so that they tend to share an XCD's L2 (speed only).  Every wait is
 // bounded: after LSTM_SEQ_TIMEOUT_TICKS without progress a workgroup raises the launch's timeout word
-// and leaves; the others see the word and leave too, so the grid always drains.  All workgroups of a
-// launch must be resident together: the host launches at most two per compute unit.
+// and leaves; the others see the word and leave too, so the grid always drains.  A workgroup that leaves
+// fills what it has not yet produced of its outputs with NaN, so the failure is in the data (loss and
+// gradients turn NaN) besides the counter below.  All workgroups of a launch must be resident together:
+// the host asks the runtime how many fit the device (seq_resident_workgroups) and refuses larger grids.
 // ------------------------------------------------------------------------------------------------
 #define SEQ_WAVES 8
 #define SEQ_MAX_CHAINS 2
@@ -446,6 +450,7 @@ struct LstmSeqArgs {
   int groups_per_chain;      // ceil(B / 32)
   unsigned* sync;            // [0] timeout word, then one arrival counter per group, SEQ_CNT_STRIDE apart
   float* xch;                // exchange: [group][2][H/8 slices][32 rows][8]
+  int debug_drop_slice;      // -1; test knob: workgroups of this slice leave at once, as if they never became resident
 };
 
 typedef __attribute__((address_space(1))) unsigned gu32_t;
@@ -488,7 +493,7 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES, SEQ_WAVES / 2) lstm_seq_fwd_ke
   const int per8 = 8 * NS;
   const int group = (int)(blockIdx.x % 8) + 8 * (int)(blockIdx.x / per8);
   const int slice = (int)(blockIdx.x % per8) / 8;
-  if (group >= ngroups) return;
+  if (group >= ngroups || slice == g.debug_drop_slice) return;
   const LstmSeqChain& c = g.ch[group / g.groups_per_chain];
   const int64_t b0 = (int64_t)(group % g.groups_per_chain) * 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -570,7 +575,16 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES, SEQ_WAVES / 2) lstm_seq_fwd_ke
         }
       }
       __syncthreads();
-      if (s_abort) return;
+      if (s_abort) {
+        if (bok) {
+          for (int s2 = step; s2 < g.T; ++s2) {
+            const int t2 = c.reverse ? g.T - 1 - s2 : s2;
+            c.hseq[(int64_t)t2 * c.step_h + b * c.ld_h + j] = __builtin_nanf("");
+            c.cseq[((int64_t)t2 * g.B + b) * H + j] = __builtin_nanf("");
+          }
+        }
+        return;
+      }
       // h of the previous step: unit u lives in slice u/8 at [row][u%8]
       const float* src = xch + (int64_t)((step - 1) & 1) * H * 32;
 #pragma unroll
@@ -652,14 +666,6 @@ extern "C" int64_t dvae_lstm_seq_ws_floats(int64_t nchains, int64_t B, int64_t H
   return SEQ_CNT_STRIDE * (1 + groups) + groups * 2 * H * 32;
 }
 
-extern "C" int dvae_lstm_seq_supported(int64_t nchains, int64_t T, int64_t B, int64_t H) {
-  if (nchains < 1 || nchains > SEQ_MAX_CHAINS || T < 1 || B < 1) return 0;
-  if (H != 128 && H != 256 && H != 512) return 0;
-  // every workgroup must be resident at once: two of these 512-thread workgroups fit a compute unit
-  // (launch bounds: at most 128 registers per lane), and there are 256 compute units
-  return nchains * ceil_div64(B, 32) * (H / 8) <= 512;
-}
-
 extern "C" int dvae_lstm_seq_fwd_f32(int64_t nchains, const float* const* xproj, const float* const* w_rec,
                                      const float* const* b_a, const float* const* b_b, const float* const* h_init,
                                      int64_t ld_hinit, const float* const* c_init, int64_t ld_cinit,
@@ -691,6 +697,12 @@ extern "C" int dvae_lstm_seq_fwd_f32(int64_t nchains, const float* const* xproj,
   const int groups = g.nchains * g.groups_per_chain;
   g.sync = (unsigned*)ws;
   g.xch = ws + SEQ_CNT_STRIDE * (1 + groups);
+  {
+    // test knob: the workgroups of one slice never show up, which is what a launch that is not fully resident
+    // looks like to the others (they run into the bound of their first wait)
+    const char* drop = getenv("DVAE_LSTM_SEQ_DEBUG_DROP_SLICE");
+    g.debug_drop_slice = drop ? atoi(drop) : -1;
+  }
   if (seq_clear(ws, groups, ST(stream)) != 0) {
     dvae_set_error("lstm_seq_fwd: clearing the counters failed: %s", hipGetErrorString(hipGetLastError()));
     return -EIO;
@@ -858,7 +870,18 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES, SEQ_WAVES / 2) lstm_seq_bwd_ke
       dhv = c.dh_ext[(int64_t)t * c.step_dh + b * c.ld_dh + j];
     }
     if (step > 0) {
-      if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)step, &s_abort)) return;
+      if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)step, &s_abort)) {
+        if (bok) {
+          for (int s2 = step; s2 < g.T; ++s2) {
+            const int t2 = c.reverse ? s2 : g.T - 1 - s2;
+            float* dg = c.dgates + ((int64_t)t2 * g.B + b) * 4 * H + j;
+            dg[0] = dg[H] = dg[2 * H] = dg[3 * H] = __builtin_nanf("");
+          }
+          if (c.dh_init) c.dh_init[b * c.ld_dhinit + j] = __builtin_nanf("");
+          if (c.dc_init) c.dc_init[b * c.ld_dcinit + j] = __builtin_nanf("");
+        }
+        return;
+      }
       gather((step - 1) & 1);
       if (cell) dhv += gathered();
     }
@@ -926,7 +949,13 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES, SEQ_WAVES / 2) lstm_seq_bwd_ke
     // (As and red are rewritten only behind the next step's wait, whose barrier every wave reaches after its reads)
   }
   if (c.dh_init != nullptr) {
-    if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)g.T, &s_abort)) return;
+    if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)g.T, &s_abort)) {
+      if (bok) {
+        c.dh_init[b * c.ld_dhinit + j] = __builtin_nanf("");
+        if (c.dc_init) c.dc_init[b * c.ld_dcinit + j] = __builtin_nanf("");
+      }
+      return;
+    }
     gather((g.T - 1) & 1);
     if (bok) {
       const float s = gathered();
@@ -1101,7 +1130,16 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_dec_fwd_kernel(LstmDecArg
     for (int l = 0; l < DEC_L; ++l) {
       const int s = t * DEC_L + l;
       if (s > 0) {
-        if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)s, &s_abort)) return;
+        if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)s, &s_abort)) {
+          if (bok) {
+            for (int s2 = s; s2 < ncells; ++s2) {
+              const int64_t row2 = ((int64_t)(s2 % DEC_L) * g.T + s2 / DEC_L) * g.B + b;
+              g.hs[row2 * H + j] = __builtin_nanf("");
+              g.cs[row2 * H + j] = __builtin_nanf("");
+            }
+          }
+          return;
+        }
       }
       // x: the cell below, or the top layer's previous output (the learned first input at the very start)
       f32x4 ax[NQ / 4];
@@ -1171,11 +1209,6 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_dec_fwd_kernel(LstmDecArg
       }
     }
   }
-}
-
-extern "C" int dvae_lstm_dec2_supported(int64_t T, int64_t B, int64_t H) {
-  if (T < 1 || B < 1 || (H != 128 && H != 256)) return 0;
-  return ceil_div64(B, 32) * (H / 8) <= 256;       // one 512-thread workgroup per compute unit, all resident
 }
 
 extern "C" int64_t dvae_lstm_dec2_ws_floats(int64_t B, int64_t H) {
@@ -1348,7 +1381,22 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_dec_bwd_kernel(LstmDecBwd
         if (l == DEC_L - 1) dhv = g.dstates[(int64_t)t * g.step_ds + b * g.ld_ds + j];
       }
       if (sigma > 0) {
-        if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)sigma, &s_abort)) return;
+        if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)sigma, &s_abort)) {
+          if (bok) {
+            for (int s2 = sigma; s2 < T * DEC_L; ++s2) {
+              const int t2 = T - 1 - s2 / DEC_L, l2 = DEC_L - 1 - s2 % DEC_L;
+              float* dg = g.dgates + (((int64_t)l2 * T + t2) * g.B + b) * 4 * H + j;
+              dg[0] = dg[H] = dg[2 * H] = dg[3 * H] = __builtin_nanf("");
+            }
+#pragma unroll
+            for (int l2 = 0; l2 < DEC_L; ++l2) {
+              g.dh0[b * g.ld_dh0 + l2 * H + j] = __builtin_nanf("");
+              g.dc0[b * g.ld_dc0 + l2 * H + j] = __builtin_nanf("");
+            }
+            g.dx0[b * H + j] = __builtin_nanf("");
+          }
+          return;
+        }
         const bool use_a = !(l == DEC_L - 1 && t == T - 1), use_b = t < T - 1;
         gather(use_a, buf_of(0, l, t), use_b, buf_of(1, l, t));
         if (cell) dhv += gathered();
@@ -1392,7 +1440,17 @@ __global__ void __launch_bounds__(64 * SEQ_WAVES) lstm_dec_bwd_kernel(LstmDecBwd
     }
   }
   // what left the chain at its end: destination step -1 (odd parity)
-  if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)(T * DEC_L), &s_abort)) return;
+  if (!seq_wait(cnt, tmo, (unsigned)NS * (unsigned)(T * DEC_L), &s_abort)) {
+    if (bok) {
+#pragma unroll
+      for (int l2 = 0; l2 < DEC_L; ++l2) {
+        g.dh0[b * g.ld_dh0 + l2 * H + j] = __builtin_nanf("");
+        g.dc0[b * g.ld_dc0 + l2 * H + j] = __builtin_nanf("");
+      }
+      g.dx0[b * H + j] = __builtin_nanf("");
+    }
+    return;
+  }
 #pragma unroll
   for (int l = 0; l < DEC_L; ++l) {
     gather(false, 0u, true, buf_of(1, l, -1));
@@ -1442,6 +1500,15 @@ extern "C" int dvae_lstm_dec2_bwd_f32(const float* const* w_ih, const float* con
 
 // Number of workgroups, on the current GPU and since the library was loaded, that gave up a bounded wait inside one
 // of the one-launch recurrence kernels (their outputs are then invalid).  Synchronises with the device.
+extern "C" int dvae_lstm_seq_timeouts_clear(void) {
+  const unsigned zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_seq_timeouts), &zero, sizeof(zero), 0, hipMemcpyHostToDevice) != hipSuccess) {
+    dvae_set_error("lstm_seq_timeouts_clear: writing the counter failed: %s", hipGetErrorString(hipGetLastError()));
+    return -EIO;
+  }
+  return 0;
+}
+
 extern "C" int64_t dvae_lstm_seq_timeouts(void) {
   unsigned v = 0;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_seq_timeouts), sizeof(v), 0, hipMemcpyDeviceToHost) != hipSuccess) {
@@ -1449,4 +1516,69 @@ extern "C" int64_t dvae_lstm_seq_timeouts(void) {
     return -EIO;
   }
   return (int64_t)v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Residency.  The one-launch kernels exchange data between workgroups inside the launch, so every workgroup of a
+// grid must be on the chip at the same time.  How many fit is a property of the device and of the compiled
+// kernels, so it is asked of the runtime (compute units x co-resident workgroups per compute unit, the smaller of
+// the forward and the backward kernel), once per device and hidden size, instead of assuming 256 compute units.
+// ------------------------------------------------------------------------------------------------
+static int seq_occupancy(const void* kernel) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 64 * SEQ_WAVES, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+// kind 0: lstm_seq_fwd / lstm_seq_bwd (H = 128, 256, 512); kind 1: the stacked decoder's pair (H = 128, 256).
+// Returns {compute units, workgroups per compute unit}, {0, 0} without a usable device.
+static void seq_residency(int kind, int64_t H, int* cus, int* per_cu) {
+  static std::mutex mu;
+  static int cache[16][2][3][2];            // [device][kind][H index] -> {cus, per_cu}; 0 = not asked yet
+  *cus = 0; *per_cu = 0;
+  const int hi = H == 128 ? 0 : H == 256 ? 1 : H == 512 ? 2 : -1;
+  int dev = -1;
+  if (hi < 0 || kind < 0 || kind > 1 || (kind == 1 && hi == 2)) return;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return; }
+  std::lock_guard<std::mutex> lock(mu);
+  int* e = cache[dev][kind][hi];
+  if (e[0] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    int f = 0, b = 0;
+    if (kind == 0) {
+      f = hi == 0 ? seq_occupancy((const void*)lstm_seq_fwd_kernel<16>) : hi == 1 ? seq_occupancy((const void*)lstm_seq_fwd_kernel<32>)
+                                                                                  : seq_occupancy((const void*)lstm_seq_fwd_kernel<64>);
+      b = hi == 0 ? seq_occupancy((const void*)lstm_seq_bwd_kernel<128>) : hi == 1 ? seq_occupancy((const void*)lstm_seq_bwd_kernel<256>)
+                                                                                   : seq_occupancy((const void*)lstm_seq_bwd_kernel<512>);
+    } else {
+      f = hi == 0 ? seq_occupancy((const void*)lstm_dec_fwd_kernel<16>) : seq_occupancy((const void*)lstm_dec_fwd_kernel<32>);
+      b = hi == 0 ? seq_occupancy((const void*)lstm_dec_bwd_kernel<128>) : seq_occupancy((const void*)lstm_dec_bwd_kernel<256>);
+    }
+    e[0] = n;
+    e[1] = f < b ? f : b;
+  }
+  *cus = e[0]; *per_cu = e[1];
+}
+
+extern "C" int64_t dvae_lstm_resident_workgroups(int kind, int64_t H, int64_t max_per_cu) {
+  int cus = 0, per_cu = 0;
+  seq_residency(kind, H, &cus, &per_cu);
+  if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = (int)max_per_cu;
+  return (int64_t)cus * per_cu;
+}
+
+extern "C" int dvae_lstm_seq_supported(int64_t nchains, int64_t T, int64_t B, int64_t H) {
+  if (nchains < 1 || nchains > SEQ_MAX_CHAINS || T < 1 || B < 1) return 0;
+  if (H != 128 && H != 256 && H != 512) return 0;
+  // every workgroup must be resident at once (at most two of these 512-thread workgroups per compute unit)
+  return nchains * ceil_div64(B, 32) * (H / 8) <= dvae_lstm_resident_workgroups(0, H, 2);
+}
+
+extern "C" int dvae_lstm_dec2_supported(int64_t T, int64_t B, int64_t H) {
+  if (T < 1 || B < 1 || (H != 128 && H != 256)) return 0;
+  return ceil_div64(B, 32) * (H / 8) <= dvae_lstm_resident_workgroups(1, H, 1);   // one workgroup per compute unit
 }

@@ -55,6 +55,7 @@ def reconstruction_metrics(model: torch.nn.Module, dataloader, device: torch.dev
     if not rows:
         raise ValueError("reconstruction_metrics: the dataloader produced no batches")
     vals = torch.stack(rows).double().cpu().numpy()              # the only read-back
+    ops.check_lstm_seq_timeouts()        # a recurrence launch that was not fully resident voids the numbers
     nan = float('nan')
     return {'mse': float(np.mean(vals[:, 0])), 'psnr': float(np.mean(vals[:, 1])), 'ssim': nan,
             'temporal_consistency': float(np.mean(vals[:, 2])), 'mse_std': float(np.std(vals[:, 0])),

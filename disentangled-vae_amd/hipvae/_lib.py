@@ -37,6 +37,7 @@ SIGNATURES = {
     'dvae_recon_loss_fwd_f32': (I, [P, P, P, P, L, L, L, I, I, P]),
     'dvae_recon_metrics_f32': (I, [P, P, P, P, L, L, L, F, P]),
     'dvae_recon_metrics_noalloc_max_elements': (L, []),
+    'dvae_recon_metrics_noalloc_init': (I, []),
     'dvae_recon_metrics_noalloc_f32': (I, [P, P, P, L, L, L, F, P]),
     'dvae_recon_loss_bwd_f32': (I, [P, P, P, P, L, L, L, I, F, P]),
     'dvae_recon_loss_bwd_logit_ws_floats': (L, [L, L]),
@@ -107,6 +108,8 @@ SIGNATURES = {
     'dvae_lstm_seq_bwd_f32': (I, [L] + [POINTER(c_void_p)] * 4 + [L, POINTER(c_void_p), L, L, POINTER(c_void_p),
                                   POINTER(c_void_p), L, POINTER(c_void_p), L, I, POINTER(c_int), L, L, L, P, P]),
     'dvae_lstm_seq_timeouts': (L, []),
+    'dvae_lstm_seq_timeouts_clear': (I, []),
+    'dvae_lstm_resident_workgroups': (L, [I, L, L]),
     'dvae_lstm_dec2_supported': (I, [L, L, L]),
     'dvae_lstm_dec2_ws_floats': (L, [L, L]),
     'dvae_lstm_dec2_fwd_f32': (I, [POINTER(c_void_p)] * 4 + [P, L, P, L, P, P, P, P, L, L, L, P, P]),

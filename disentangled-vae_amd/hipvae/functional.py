@@ -63,8 +63,24 @@ def _seq_ok(chains: int, T: int, B: int, H: int) -> bool:
     most one workgroup per compute unit are used there (single process: up to two)."""
     if not (USE_SEQ_KERNELS and ops.lstm_seq_supported(chains, T, B, H)):
         return False
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-        return chains * ((B + 31) // 32) * (H // 8) <= 256
+    if _several_ranks():
+        return chains * ((B + 31) // 32) * (H // 8) <= ops.lstm_resident_workgroups(0, H, 1)
+    return True
+
+
+def _several_ranks() -> bool:
+    return (torch.distributed.is_available() and torch.distributed.is_initialized()
+            and torch.distributed.get_world_size() > 1)
+
+
+def _dec2_ok(T: int, B: int, H: int) -> bool:
+    """The same question for the stacked decoder's one-launch kernels.  They hold a whole compute unit each, so with
+    several ranks (collectives' kernels on the same chip) only grids of at most one workgroup per two compute
+    units are used."""
+    if not (USE_SEQ_KERNELS and ops.lstm_dec2_supported(T, B, H)):
+        return False
+    if _several_ranks():
+        return ((B + 31) // 32) * (H // 8) <= ops.lstm_resident_workgroups(1, H, 1) // 2
     return True
 
 
@@ -684,7 +700,7 @@ class LSTMDecoder(torch.autograd.Function):
         # x W_ih^T + h W_hh^T = h (W_ih + W_hh)^T and the step is H deep instead of 2H
         w_comb = (w[0] + w[1]) if (L == 1 and T > 1) else None
         seq = w_comb is not None and _seq_ok(1, T - 1, B, H)
-        dec2 = L == 2 and USE_SEQ_KERNELS and ops.lstm_dec2_supported(T, B, H)
+        dec2 = L == 2 and _dec2_ok(T, B, H)
         if dec2:
             # both layers' cells of all T steps as one chain in one launch, the four weight slices in registers
             ops.lstm_dec2_fwd(w, h0, c0, init_c.view(-1), gates, hs, cs)
@@ -722,7 +738,7 @@ class LSTMDecoder(torch.autograd.Function):
         dh0 = _empty(B, L * H, like=h0)
         dc0 = _empty(B, L * H, like=h0)
         dx0 = _empty(B, H, like=h0)
-        dec2 = L == 2 and USE_SEQ_KERNELS and ops.lstm_dec2_supported(T, B, H)
+        dec2 = L == 2 and _dec2_ok(T, B, H)
         if dec2:
             # the whole chain of cells backwards in one launch
             ops.lstm_dec2_bwd(weights, gates, cs, c0, dstates.contiguous(), dg, dh0, dc0, dx0)

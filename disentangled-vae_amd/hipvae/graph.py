@@ -19,6 +19,21 @@ import torch.distributed as dist
 from . import rng
 
 
+_CAPTURE_STREAMS = {}
+
+
+def capture_stream(device=None) -> torch.cuda.Stream:
+    """The one stream per device on which every step is warmed up and captured.  Autograd keeps the
+    gradient-accumulation node it made for a parameter, together with the stream it first ran on, for as long
+    as anything refers to the graph; warming up or capturing a later step (another batch shape) on a different
+    stream would put a cross-stream wait in front of every gradient (torch warns about exactly that)."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    s = _CAPTURE_STREAMS.get(idx)
+    if s is None:
+        s = _CAPTURE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return s
+
+
 class GraphedTrainStep:
 
     def __init__(self, model: torch.nn.Module, optimizer, loss_of: Callable, example_video: torch.Tensor,
@@ -39,7 +54,7 @@ class GraphedTrainStep:
         dyn_snap = dyn.detach().clone()
         # a run with injected normal draws: the captured step reads them from buffers of its own
         inject = rng.injecting()
-        side = torch.cuda.Stream()
+        side = capture_stream(example_video.device)
         side.wait_stream(torch.cuda.current_stream())
         rehearsed = None
         with torch.cuda.stream(side):
@@ -48,10 +63,7 @@ class GraphedTrainStep:
                     self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        # capture goes on the stream the warm-up ran on: the gradient-accumulation nodes that autograd made
-        # for the parameters during warm-up stay alive and keep that stream; recording the step on another one
-        # would put a cross-stream wait in front of every gradient (torch warns about exactly that)
-        self._capture_stream = side
+        self._capture_stream = side          # capture goes on the stream the warm-up ran on (see capture_stream)
         # the draw buffers exist before capture begins (see rng.draw_slots), one per draw of the rehearsed step
         self.eps_slots = [torch.zeros_like(b) for b in rehearsed] if inject else None
         with (rng.draw_slots(self.eps_slots) if inject else contextlib.nullcontext()):
@@ -116,7 +128,7 @@ class GraphedForward:
         self.model = model
         self.fn = fn if fn is not None else (lambda m, v: m(v))
         self.static_in = example.detach().clone()
-        side = torch.cuda.Stream()
+        side = capture_stream(example.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(warmup):

@@ -854,12 +854,22 @@ def lstm_seq_timeouts() -> int:
     return int(n)
 
 
+def lstm_resident_workgroups(kind: int, H: int, max_per_cu: int = 0) -> int:
+    """Workgroups of the one-launch recurrence kernels (kind 0: one layer; 1: the stacked decoder) that fit the
+    current device together, at most max_per_cu per compute unit when that is > 0."""
+    return int(lib.dvae_lstm_resident_workgroups(kind, H, max_per_cu))
+
+
 def check_lstm_seq_timeouts():
+    """Raises if a workgroup of a one-launch recurrence kernel gave up a wait since the last check (the counter
+    is cleared, so the next check reports new failures only).  Synchronises."""
     n = lstm_seq_timeouts()
     if n:
+        check(lib.dvae_lstm_seq_timeouts_clear(), 'lstm_seq_timeouts_clear')
         raise RuntimeError(f"{n} workgroup(s) of a one-launch LSTM kernel ran into the bound of a wait: the launch was "
                            "not fully resident (another kernel held compute units for more than 200 ms); results of "
-                           "that step are invalid.  DVAE_SEQ_LSTM=0 selects one launch per step.")
+                           "that step are invalid (the kernels filled them with NaN).  DVAE_SEQ_LSTM=0 selects one "
+                           "launch per step.")
 
 
 def lstm_dec2_supported(T: int, B: int, H: int) -> bool:

@@ -344,6 +344,7 @@ class Trainer:
                 # the only per-step synchronisation; with several ranks the logged values are the mean
                 # over ranks (every rank takes part in the collective, rank 0 writes)
                 cur = self._unpack(last, self._rank_mean(packed.clone()).cpu())
+                hip_ops.check_lstm_seq_timeouts()      # the device is idle here anyway
             if self.rank == 0 and self.global_step % t.log_every == 0:
                 for k, v in cur.items():
                     self.writer.add_scalar(f'train/{k}', v, self.global_step)

@@ -105,6 +105,11 @@ int dvae_recon_metrics_f32(const float* recon, const float* target, float* out, 
  *      calls ordered on one stream do not.  Nothing needs clearing between calls. */
 #define DVAE_NOALLOC_MAX_ELEMENTS ((int64_t)1 << 31)
 int64_t dvae_recon_metrics_noalloc_max_elements(void);
+/* Locates the array on the current device now instead of at the first call there.  A caller that will issue
+ * dvae_recon_metrics_noalloc_f32 under HIP graph capture calls this once per device beforehand: the look-up is a
+ * runtime call (it may load the library's code object) that a capturing stream does not allow.  No counterpart in
+ * the reference. */
+int dvae_recon_metrics_noalloc_init(void);
 int dvae_recon_metrics_noalloc_f32(const float* recon, const float* target, float* out, int64_t B, int64_t T,
                                    int64_t P, float max_val, dvae_stream_t stream);
 
@@ -415,11 +420,20 @@ int dvae_skinny_gemm_nt_f32(const float* a, int64_t ld_a, const float* wt, int64
  *      hseq + t*step_h + b*ld_h.  The recurrent weights stay in registers for all T steps: a group of 32
  *      batch rows is served by H/8 workgroups that exchange the hidden state through ws inside the launch.
  *      All workgroups must be resident together, so dvae_lstm_seq_supported() admits H in {128, 256, 512}
- *      and nchains*ceil(B/32)*(H/8) <= 512 only; otherwise -EINVAL (use the per-step calls).
+ *      and nchains*ceil(B/32)*(H/8) <= dvae_lstm_resident_workgroups(0, H, 2) only (512 on an MI355X with all
+ *      256 compute units; 0 without a GPU); otherwise -EINVAL (use the per-step calls).
  *      ws: dvae_lstm_seq_ws_floats(nchains, B, H) floats, 256-byte aligned; ws[0] (read as unsigned) is
- *      non-zero after the launch if a wait inside it ran into its 200 ms bound (outputs are then invalid).
+ *      non-zero after the launch if a wait inside it ran into its 200 ms bound.  The outputs are then invalid,
+ *      and say so: a workgroup that gives up fills the part of hseq / cseq (backward: dgates, dh_init, dc_init)
+ *      it has not produced yet with NaN.
  *      Not to be run concurrently with another launch of itself unless both fit the chip together. */
 int dvae_lstm_seq_supported(int64_t nchains, int64_t T, int64_t B, int64_t H);
+/* How many workgroups of the one-launch recurrence kernels (kind 0: dvae_lstm_seq_fwd/bwd_f32, kind 1:
+ * dvae_lstm_dec2_fwd/bwd_f32) for hidden size H can be resident at once on the current device: its compute-unit
+ * count x the occupancy the runtime reports for the compiled kernels (the smaller of forward and backward), at most
+ * max_per_cu per compute unit when max_per_cu > 0 (callers that share the device with other kernels, e.g. RCCL's,
+ * leave room that way).  No counterpart in the reference. */
+int64_t dvae_lstm_resident_workgroups(int kind, int64_t H, int64_t max_per_cu);
 int64_t dvae_lstm_seq_ws_floats(int64_t nchains, int64_t B, int64_t H);
 int dvae_lstm_seq_fwd_f32(int64_t nchains, const float* const* xproj, const float* const* w_rec,
                           const float* const* b_a, const float* const* b_b, const float* const* h_init,
@@ -454,8 +468,8 @@ int dvae_lstm_seq_bwd_f32(int64_t nchains, const float* const* w_rec, const floa
  *      same [H] vector for every row, at t = 0) and x = h_{0,t} for layer 1; initial states h0 / c0 [B][2H] (layer l
  *      in columns l*H..).  Host arrays of two device pointers (layer 0, layer 1), weights [4H][H], biases [4H].
  *      Outputs gates [2][T][B][4H] (activated), hs / cs [2][T][B][H].  dvae_lstm_dec2_supported(): H in {128, 256}
- *      and ceil(B/32)*(H/8) <= 256 (every workgroup resident, one per compute unit); otherwise -EINVAL (use the
- *      per-step calls).  ws: dvae_lstm_dec2_ws_floats(B, H) floats, 256-byte aligned, ws[0] as in dvae_lstm_seq_fwd_f32. */
+ *      and ceil(B/32)*(H/8) <= dvae_lstm_resident_workgroups(1, H, 1) (every workgroup resident, one per compute
+ *      unit: 256 on a full MI355X); otherwise -EINVAL (use the per-step calls).  ws: dvae_lstm_dec2_ws_floats(B, H) floats, 256-byte aligned, ws[0] as in dvae_lstm_seq_fwd_f32. */
 int dvae_lstm_dec2_supported(int64_t T, int64_t B, int64_t H);
 int64_t dvae_lstm_dec2_ws_floats(int64_t B, int64_t H);
 int dvae_lstm_dec2_fwd_f32(const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
@@ -472,9 +486,10 @@ int dvae_lstm_dec2_bwd_f32(const float* const* w_ih, const float* const* w_hh, c
                            int64_t T, int64_t B, int64_t H, float* ws, dvae_stream_t stream);
 /* Every wait inside the one-launch recurrence kernels is bounded (200 ms: a workgroup that never becomes resident
  * must not hang the GPU); a launch in which one ran out leaves invalid outputs.  Number of workgroups that gave up
- * on the current GPU since the library was loaded; synchronises with the device, so call it where the caller
- * synchronises anyway (end of an epoch, a logging interval). */
+ * on the current GPU since the library was loaded (or since the last dvae_lstm_seq_timeouts_clear()); synchronises
+ * with the device, so call it where the caller synchronises anyway (end of an epoch, a logging interval). */
 int64_t dvae_lstm_seq_timeouts(void);
+int dvae_lstm_seq_timeouts_clear(void);
 
 /* ---- optimiser (torch.optim.Adam with L2 weight decay and nn.utils.clip_grad_norm_ as called at
  *      training/trainer.py:56-61,198-204).  Host arrays of n device pointers / sizes.

@@ -11,6 +11,8 @@ Tolerances: fp32 kernels vs fp64, relative L2 <= 5e-6 (K up to 8192 accumulated 
 bars as in test_models_gpu.py (outputs and losses 1e-4 relative, per-tensor gradients
 max(1e-4, 2 x the fp32 CPU restatement's own error against fp64)).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -146,6 +148,24 @@ def test_gemm_at_bench_size(ops, M, N, K):
     assert rel_err(out, base.double() + d.double().t() @ a.double()) < 5e-6
 
 
+# bf16-MFMA variant, full width, batch 256: bar on the per-tensor gradient error = 1.5 x the worst value measured on
+# MI355X (profiles/r3_parity_b256.txt)
+BF16_GRAD_BAR = 2e-1
+
+
+def _record(title, header, rows):
+    """DVAE_PARITY_REPORT=<file>: append the full table behind an assertion to that file (the tables committed under
+    profiles/ are made this way); nothing otherwise."""
+    path = os.environ.get('DVAE_PARITY_REPORT')
+    if not path:
+        return
+    with open(path, 'a') as f:
+        f.write(title + '\n' + ' | '.join(header) + '\n')
+        for r in rows:
+            f.write(' | '.join(str(x) for x in r) + '\n')
+        f.write('\n')
+
+
 class _KinkAt(torch.autograd.Function):
     """LeakyReLU(0.2) with the exact forward value and a derivative that switches at x = thr instead of 0."""
 
@@ -186,10 +206,12 @@ def _oracle_step(kind, sd, video, eps, tcfg, beta, layers, dtype, kink=None):
     return keys, out, {k: float(v.detach()) for k, v in loss.items() if torch.is_tensor(v) and v.numel() == 1}, grads, ns
 
 
-@pytest.mark.parametrize('kind,B', [('disentangled', 256), ('lstm', 64), ('baseline', 256)])
-def test_training_step_at_bench_batch_against_oracle(kind, B):
+@pytest.mark.parametrize('name,B,T,size', [('disentangled', 256, 20, 64), ('lstm', 64, 20, 64), ('baseline', 256, 20, 64),
+                                           ('disentangled_128_wide40', 2, 40, 128)])
+def test_training_step_at_bench_batch_against_oracle(name, B, T, size):
     """One whole training step at the benchmark's batch and real layer widths (T=20, 64x64): every launch
-    the benchmark times is on this path.  HIP outputs, losses, gradients and BatchNorm buffers vs the fp64
+    the benchmark times is on this path; and the 128x128 configuration at its own widths and clip length (40 frames:
+    the 39- and 40-step recurrences in one launch each, five-level encoder and decoder).  HIP outputs, losses, gradients and BatchNorm buffers vs the fp64
     oracle, with the fp32 CPU restatement's own distance from fp64 as the yard-stick for gradients.
 
     The gradient is discontinuous where a LeakyReLU input is zero.  With 10^5..10^8 activations per layer
@@ -202,19 +224,19 @@ def test_training_step_at_bench_batch_against_oracle(kind, B):
     import models
     from hipvae import rng
     from test_models_gpu import FULL, SETTINGS, as_dict, loss_of, rel
-    T, size = 20, 64
+    kind = name.split('_')[0]
     torch.manual_seed(0)
-    m = models.get_model(kind, in_channels=1, **FULL[kind])
+    m = models.get_model(kind, in_channels=1, **FULL[name])
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     gen = torch.Generator().manual_seed(1)
     video = (torch.rand(B, T, 1, size, size, generator=gen) > 0.9).float() * torch.rand(B, T, 1, size, size,
                                                                                          generator=gen)
-    dim = FULL[kind].get('content_dim', FULL[kind].get('latent_dim'))
+    dim = FULL[name].get('content_dim', FULL[name].get('latent_dim'))
     eps = [torch.randn(B, dim, generator=torch.Generator().manual_seed(100 + k)) for k in range(2)]
     tcfg = dict(SETTINGS['tcfg'][kind])
     if kind == 'disentangled':
         tcfg.update(beta_content=4.0, beta_motion=4.0)           # the benchmark's beta
-    layers = FULL[kind].get('lstm_layers', 1)
+    layers = FULL[name].get('lstm_layers', 1)
     keys, oout, oloss, ograds, ns = _oracle_step(kind, sd, video, eps, tcfg, 4.0, layers, torch.float64)
     _, _, _, ograds32, _ = _oracle_step(kind, sd, video, eps, tcfg, 4.0, layers, torch.float32)
     _, _, _, g_lo, _ = _oracle_step(kind, sd, video, eps, tcfg, 4.0, layers, torch.float64, kink=-1e-5)
@@ -237,6 +259,12 @@ def test_training_step_at_bench_batch_against_oracle(kind, B):
         kink = rel(hi.numpy(), lo.numpy())
         report.append((r / max(1e-4, 2 * own, kink), k, r, own, kink))
     report.sort(reverse=True)
+    _record(f'{name} B={B} T={T} {size}x{size} fp32: per-tensor gradient error against the fp64 oracle (relative L2), the fp32 CPU '
+            f'restatement\'s own error, and the kink sensitivity; bar = max(1e-4, 2 x own, kink)',
+            ['err/bar', 'tensor', 'err', 'own fp32 err', 'kink sensitivity', 'term that sets the bar'],
+            [(f'{q:.3f}', k, f'{r:.3e}', f'{own:.3e}', f'{kk:.3e}',
+              'kink' if kk >= max(1e-4, 2 * own) else ('2 x own' if 2 * own > 1e-4 else '1e-4'))
+             for q, k, r, own, kk in report])
     print(f'{kind} B={B}: worst gradient tensors (err, fp32 restatement own err, kink sensitivity):',
           [(k, f'{r:.2e}', f'{own:.2e}', f'{kk:.2e}') for _, k, r, own, kk in report[:6]])
     assert report[0][0] <= 1.0, report[0]
@@ -283,6 +311,9 @@ def test_bf16_training_step_at_bench_batch():
     named = dict(m.named_parameters())
     errs = {k: rel(named[k].grad.cpu().numpy(), og.numpy()) for k, og in zip(keys, ograds)}
     worst = max(errs, key=errs.get)
+    _record(f'{kind} B={B} bf16 MFMA operands: per-tensor gradient error against the fp64 oracle (relative L2); '
+            f'median {np.median(list(errs.values())):.3e}, worst {errs[worst]:.3e} ({worst}); bar {BF16_GRAD_BAR}',
+            ['tensor', 'err'], [(k, f'{v:.3e}') for k, v in sorted(errs.items(), key=lambda kv: -kv[1])])
     print(f'bf16 B={B}: gradient rel-L2 error median {np.median(list(errs.values())):.3e}, '
           f'worst {errs[worst]:.3e} ({worst})')
-    assert errs[worst] < 2e-1, (worst, errs[worst])
+    assert errs[worst] < BF16_GRAD_BAR, (worst, errs[worst])

@@ -619,6 +619,41 @@ def test_lstm_seq_fwd_whole_recurrence_in_one_launch(ops, T, B, H, chains):
     assert torch.equal(first, hseq)
 
 
+def test_lstm_seq_launch_that_is_not_fully_resident_is_reported(ops, monkeypatch):
+    """A one-launch recurrence whose workgroups are not all on the chip: the others run into the bound of their
+    first wait (200 ms), the launch drains, the missing part of the outputs is NaN, the per-GPU counter is raised
+    and the check the Trainer makes turns it into an error -- once: the counter is cleared by the report.  The
+    missing workgroups are forced by a test knob (one slice of every group leaves at once)."""
+    T, B, H = 4, 32, 128
+    assert ops.lstm_seq_timeouts() == 0
+    # the residency the library admits comes from the device, not from a constant
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert ops.lstm_resident_workgroups(0, H, 1) == cus and ops.lstm_resident_workgroups(1, H, 1) == cus
+    assert ops.lstm_resident_workgroups(0, 256, 0) in (cus, 2 * cus)
+    assert not ops.lstm_seq_supported(2, T, 32 * (2 * cus // 32 + 1), 256)        # one group too many
+    spec = dict(xproj=dev(rnd(T, B, 4 * H, seed=1)), w_rec=dev(rnd(4 * H, H, seed=2, scale=0.08)),
+                gates=torch.empty(T, B, 4 * H, device='cuda'), hseq=torch.zeros(T, B, H, device='cuda'),
+                cseq=torch.zeros(T, B, H, device='cuda'))
+    monkeypatch.setenv('DVAE_LSTM_SEQ_DEBUG_DROP_SLICE', '3')
+    ws = ops.lstm_seq_fwd([spec], T, B, H)
+    torch.cuda.synchronize()
+    monkeypatch.delenv('DVAE_LSTM_SEQ_DEBUG_DROP_SLICE')
+    assert int(ws[:1].view(torch.int32).item()) != 0
+    h = spec['hseq']
+    assert torch.isfinite(h[0, :, :24]).all() and torch.isfinite(h[0, :, 32:]).all()      # step 0 needs no hand-off
+    assert torch.isnan(h[1:, :, :24]).all() and torch.isnan(h[1:, :, 32:]).all()          # nothing after it arrived
+    assert ops.lstm_seq_timeouts() >= 1
+    with pytest.raises(RuntimeError, match='not fully resident'):
+        ops.check_lstm_seq_timeouts()
+    assert ops.lstm_seq_timeouts() == 0
+    ops.check_lstm_seq_timeouts()
+    # and the same launch without the knob is healthy again
+    ws = ops.lstm_seq_fwd([spec], T, B, H)
+    torch.cuda.synchronize()
+    assert int(ws[:1].view(torch.int32).item()) == 0 and torch.isfinite(spec['hseq']).all()
+    assert ops.lstm_seq_timeouts() == 0
+
+
 @pytest.mark.parametrize('T,B,H', [(19, 32, 256), (6, 40, 128)])
 def test_lstm_seq_fwd_from_an_initial_state_without_input(ops, T, B, H):
     """the decoder's form: no input projection, strided initial state, combined weights"""

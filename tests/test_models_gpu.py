@@ -248,6 +248,9 @@ FULL['disentangled_128_wide'] = dict(content_dim=128, motion_dim=128, content_ch
                                      motion_channels=[32, 64, 64], decoder_channels=[512, 512, 256, 128, 64],
                                      content_feature_dim=512, motion_feature_dim=512, lstm_hidden=256, lstm_layers=1,
                                      bidirectional=True, sequence_length=3)
+# ... and at the configuration's own clip length: 39 / 40-step recurrences in one launch each (run by
+# test_bench_size_gpu.py, whose bar knows about LeakyReLU's kink)
+FULL['disentangled_128_wide40'] = dict(FULL['disentangled_128_wide'], sequence_length=40)
 CASES = [('disentangled', 4, 20, 64), ('lstm', 4, 20, 64), ('baseline', 4, 20, 64),
          ('disentangled_128_narrow', 2, 6, 128), ('disentangled_128_wide', 4, 3, 128),
          # ragged: odd batch with few frames, a single clip of two frames, single-frame clips

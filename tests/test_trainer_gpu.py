@@ -455,6 +455,56 @@ def test_gradsync_on_rccl_single_rank_equals_plain_step():
         assert torch.equal(graphed[k], graphed_dp[k]), (k, (graphed[k].float() - graphed_dp[k].float()).abs().max().item())
 
 
+def test_dp_graph_step_in_bf16_at_batch_256_equals_the_one_graph_step():
+    """The combination BASELINE's data-parallel configuration names, as one thing: the captured data-parallel step
+    (three graphs around the RCCL all-reduces, here on a one-rank group, where averaging is the identity) with bf16
+    MFMA operands, full-width DisentangledVAE, 256 clips.  Three steps give the parameters of the one-graph bf16
+    step bit for bit (same kernels in the same order; only the graph boundaries and the flat gradient buffer
+    differ)."""
+    import socket
+    import torch.distributed as dist
+    import models
+    from hipvae import losses, ops, rng
+    from hipvae.graph import GraphedDataParallelStep, GraphedTrainStep
+    from hipvae.optim import FusedAdam
+    batches = [synthetic_clips(256, 20, 300 + i).cuda() for i in range(2)]
+    loss_of = lambda mm, v: losses.disentangled_loss(mm(v), v, beta=4.0, beta_content=4.0, beta_motion=4.0,
+                                                     recon_loss_type='bce', independence_weight=0.02,
+                                                     temporal_weight=0.05)
+
+    def run(parallel):
+        torch.manual_seed(21)
+        m = models.get_model('disentangled', sequence_length=20).cuda().train()
+        opt = FusedAdam(m.parameters(), lr=1e-4, weight_decay=1e-5)
+        step = (GraphedDataParallelStep if parallel else GraphedTrainStep)(m, opt, loss_of, batches[0], gradient_clip=5.0)
+        out = None
+        for i in range(3):
+            out = step(batches[i % 2])
+        assert torch.isfinite(out['total_loss'])
+        return {k: v.clone() for k, v in m.state_dict().items()}, float(out['total_loss'])
+
+    orig = rng.draw_like
+    rng.draw_like = lambda t: torch.zeros_like(t)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    ops.set_precision('bf16')
+    try:
+        one, loss_one = run(False)
+        dp, loss_dp = run(True)
+        assert ops.lstm_seq_timeouts() == 0
+    finally:
+        ops.set_precision('fp32')
+        dist.destroy_process_group()
+        rng.draw_like = orig
+    assert loss_one == loss_dp
+    for k in one:
+        assert torch.equal(one[k], dp[k]), (k, (one[k].float() - dp[k].float()).abs().max().item())
+
+
 def test_trainer_says_why_a_step_is_not_replayed(tmp_path, capsys):
     """A loss function the Trainer does not know may hold beta as a launch constant: the step then runs as eager
     launches and the reason is printed once and kept."""

@@ -61,6 +61,27 @@ def test_no_alloc_entry_point_matches_the_workspace_one_on_two_calls_in_a_row():
     assert torch.equal(o.cpu(), refs[1].cpu())
 
 
+def test_no_alloc_entry_point_under_graph_capture():
+    """What the entry point is for: recorded into a HIP graph (after the explicit per-device set-up call, which is the
+    only part that may not run under capture) and replayed on two different inputs, against the workspace variant."""
+    from hipvae._lib import lib
+    assert lib.dvae_recon_metrics_noalloc_init() == 0, lib.dvae_last_error()
+    a, b = _clips(5, 4, 64, 11), _clips(5, 4, 64, 12)
+    recon, target = torch.empty_like(a[0]), torch.empty_like(a[1])
+    out = torch.full((3,), -1.0, device='cuda')
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        _no_alloc(lib, recon, target, 1.0, out)
+    for clips in (a, b):
+        recon.copy_(clips[0])
+        target.copy_(clips[1])
+        g.replay()
+        ref = _with_workspace(lib, *clips, 1.0)
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), ref.cpu())
+
+
 def test_no_alloc_entry_point_rejects_what_it_cannot_do():
     from hipvae._lib import lib
     recon, target = _clips(2, 3, 32, 4)
