@@ -35,12 +35,61 @@ PEAK_HBM_GBS = 8000.0
 # training step) of the three JSON configurations at 20 frames of 64 x 64.  The baseline model decodes one latent
 # per clip into twenty identical frames: its decoder counts once per clip (0.286 encoder + 0.272 / 20 decoder),
 # as it is executed, not twenty times as the reference runs it (0.558).
-GFLOP_PER_CLIP = {'disentangled_simple.json': (1.524, 4.571), 'lstm_simple.json': (2.397, 7.191),
-                  'small_baseline.json': (0.299, 0.898)}
+# (gflop_per_clip() derives them from a configuration's layer list: 1.524 / 4.571 for disentangled_simple.json, 2.397 /
+# 7.191 for lstm_simple.json, 0.299 / 0.898 for small_baseline.json, 44.21 / 132.64 for the 128 x 128 x 40 one.)
 PRECISION_LABEL = {'fp32': ('f32', 'fp32 MFMA'),
                    'bf16': ('bf16', 'bf16 MFMA operands, fp32 accumulate and storage'),
                    'fp32_split': ('f32', 'fp32 products from a three-term bf16 split of each operand '
                                          '(Linear layers, tiled convolutions), fp32 MFMA elsewhere')}
+
+
+def gflop_per_clip(cfg):
+    """(forward, training) algorithmic GFLOP per clip of a configuration: 2 FLOP per multiply-accumulate of every
+    convolution (Ho*Wo*Cout*16*Cin), transposed convolution (4 sub-pixel phases of Hi*Wi*Cout*4*Cin), Linear layer and
+    LSTM gate product, nothing else; training = 3 x forward (data and weight gradient of every product)."""
+    m, d = cfg['model'], cfg['data']
+    T, S = d['sequence_length'], d['frame_size']
+    F, H, L = m['feature_dim'], m['lstm_hidden'], m['lstm_layers']
+    D = 2 if m['bidirectional'] else 1
+
+    def conv_stack(channels, cin=1):
+        macs, s = 0, S
+        for c in channels:
+            s //= 2
+            macs += s * s * c * 16 * cin
+            cin = c
+        return macs, cin * s * s
+
+    def decoder_frame(width_in):
+        ch = m['decoder_channels']
+        macs, s = width_in * ch[0] * 16, 4
+        for a, b in zip(ch[:-1], ch[1:]):
+            s *= 2
+            macs += s * s * b * 4 * a
+        s *= 2
+        return macs + s * s * 4 * ch[-1]
+
+    enc_lstm = sum(D * 4 * H * ((F if l == 0 else D * H) + H) for l in range(L))      # per step
+    dec_lstm = L * 4 * H * 2 * H                                                       # per step
+    kind = m['model_type']
+    if kind == 'disentangled':
+        cd, md = m['content_dim'], m['motion_dim']
+        content, flat = conv_stack(m['encoder_channels'])
+        content += flat * F + 2 * F * cd
+        motion, flat = conv_stack(m['motion_channels'])
+        motion += flat * F
+        macs = content + (T - 1) * (motion + enc_lstm) + 2 * D * H * md
+        macs += 2 * (cd + md) * H * L + T * (dec_lstm + H * F + decoder_frame(F + cd))
+    else:
+        lat = m['latent_dim']
+        frame, flat = conv_stack(m['encoder_channels'])
+        frame += flat * F
+        if kind == 'baseline':
+            macs = T * (frame + 2 * F * lat) + decoder_frame(lat)        # one decoded frame per clip, as executed
+        else:
+            macs = T * (frame + enc_lstm) + 2 * D * H * lat
+            macs += 2 * lat * H * L + T * (dec_lstm + H * F + decoder_frame(F))
+    return round(2 * macs / 1e9, 3), round(6 * macs / 1e9, 3)
 
 
 def load_config(name):
@@ -338,7 +387,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     use_dp = world > 1 or args.force_dist
+    saved_stdout = None
     if use_dp:
+        # RCCL prints a version banner on stdout when it creates its communicator: everything the libraries write
+        # goes to stderr, stdout carries the one result line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
@@ -514,7 +569,7 @@ def main():
         'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': dtype_label, 'data': 'synthetic',
         'config': {'workload': f"{cfg['name']} ({args.config}) {args.mode} step, beta=4, {T}x{size}x{size} clips, "
-                               f"batch {B}/GPU, {prec_label}, {('batches from pinned host memory (' + args.host_batches + '), ') if args.host_batches else ''}{('hipGraph replay' + (' (decoder-side backward graph, all-reduce of its gradients beside the encoder-side backward graph, all-reduce of the rest, update graph)' if use_dp else '')) if use_graph else 'eager launches'}",
+                               f"batch {B}/GPU, {prec_label}, {('batches from pinned host memory (' + args.host_batches + '), ') if args.host_batches else ''}{('hipGraph replay' + (' (one graph per backward stage -- decoder side, encoders above their convolution stacks, convolution stacks -- the gradients of each stage all-reduced beside the next stage, update graph)' if use_dp else '')) if use_graph else 'eager launches'}",
                    'global_batch': B * world, 'params': n_params,
                    'parallelism': f'dp{world}'},
     }
@@ -525,11 +580,11 @@ def main():
         result['rccl_world_size'] = dist.get_world_size()
         if graph_fallback:
             result['graph_fallback'] = graph_fallback[0][:300]
-        result['config']['collective'] = ('two all-reduces (AVG) per step over RCCL on a side stream: decoder-side gradients while the encoders are still in backward, then the rest'
+        result['config']['collective'] = ('three all-reduces (AVG) per step over RCCL on a side stream: decoder-side gradients (16 MB) and the encoders\' Linear / LSTM gradients (33 MB) travel beside the backward stages that follow them; only the convolution filters (3 MB) are reduced after backward has ended'
                                           if use_graph else 'bucketed all-reduces (AVG) over RCCL, overlapped with backward')
-    gf = GFLOP_PER_CLIP.get(args.config)
+    gf = gflop_per_clip(cfg)
     whole = None
-    if gf is not None and size == 64 and T == 20:
+    if gf is not None:
         tfl = gf[1 if args.mode == 'train' else 0] * B * world / (elapsed / args.steps) / 1e3
         whole = {'achieved': round(tfl, 2), 'peak': peak_tflops * world, 'unit': 'TFLOP/s',
                  'frac': round(tfl / (peak_tflops * world), 4),
@@ -563,8 +618,12 @@ def main():
     if args.mode == 'train' and not args.no_extras and world == 1:
         # the same job's inference rate (eval-mode forward, no_grad) and its bf16-MFMA variant
         el, _ = measure(make_infer_step(), args.steps, min(args.warmup, 3))
+        itfl = gf[0] * B * world / (el / args.steps) / 1e3
         result['inference'] = {'value': round(world * B * args.steps / el, 2), 'unit': 'clips/s',
                                'ms_per_step': round(el / args.steps * 1e3, 3),
+                               'roofline': {'bound': 'mfma', 'achieved': round(itfl, 2), 'peak': peak_tflops * world,
+                                            'unit': 'TFLOP/s', 'frac': round(itfl / (peak_tflops * world), 4),
+                                            'gflop_per_clip': gf[0]},
                                'workload': f'eval-mode forward (no_grad), batch {B}/GPU, {prec_label}'
                                            + (', hipGraph replay' if args.graph != 0 else '')}
         model.train()
@@ -589,27 +648,32 @@ def main():
                             'not the headline value'}
             ops.set_precision('fp32')
         if args.config == 'disentangled_simple.json' and args.precision == 'fp32':
-            # BASELINE configurations 2 and 3 (batch 32 on one GPU, fp32) and the small baseline beside them
-            others = {}
-            for cfg_name in ('disentangled_simple.json', 'lstm_simple.json', 'small_baseline.json'):
+            # BASELINE configurations 2 and 3 (batch 32 on one GPU, fp32) and the small baseline beside them; then
+            # LSTMVAE at the headline's batch and the 128 x 128 x 40 configuration (BASELINE configuration 5) at 32
+            from hipvae.graph import GraphedTrainStep
+
+            def graphed_rate(cfg_name, batch):
                 c2 = load_config(cfg_name)
                 k2, t2 = c2['model']['model_type'], c2['training']
+                T2, S2 = c2['data']['sequence_length'], c2['data']['frame_size']
                 torch.manual_seed(0)
                 m2 = models.get_model(k2, **model_kwargs(c2)).to(dev).train()
                 o2 = FusedAdam(m2.parameters(), lr=t2['learning_rate'], betas=(t2['beta1'], t2['beta2']),
                                weight_decay=t2['weight_decay'])
-                r2 = [synthetic_clips(32, 20, 64, 7000 + i).to(dev) for i in range(4)]
-                from hipvae.graph import GraphedTrainStep
-                g2 = GraphedTrainStep(m2, o2, lambda mm, v, k2=k2, t2=t2: loss_call(k2, L, mm(v), v, t2, beta), r2[0],
+                r2 = [synthetic_clips(batch, T2, S2, 7000 + i).to(dev) for i in range(4)]
+                g2 = GraphedTrainStep(m2, o2, lambda mm, v: loss_call(k2, L, mm(v), v, t2, beta), r2[0],
                                       gradient_clip=t2['gradient_clip'])
                 el, _ = measure(lambda i: g2(r2[i % 4]), args.steps, args.warmup)
                 ms2 = el / args.steps * 1e3
-                gf2 = GFLOP_PER_CLIP[cfg_name][1]
-                others[cfg_name] = {'batch': 32, 'ms_per_step': round(ms2, 3), 'value': round(32 / ms2 * 1e3, 1),
-                                    'unit': 'clips/s',
-                                    'whole_step_frac': round(gf2 * 32 / ms2 / PEAK_FP32_MFMA_TFLOPS, 4)}
-                del g2, m2, o2, r2
+                gf2 = gflop_per_clip(c2)[1]
+                return {'batch': batch, 'clip': f'{T2}x{S2}x{S2}', 'ms_per_step': round(ms2, 3),
+                        'value': round(batch / ms2 * 1e3, 1), 'unit': 'clips/s', 'gflop_per_clip': gf2,
+                        'whole_step_frac': round(gf2 * batch / ms2 / PEAK_FP32_MFMA_TFLOPS, 4)}
+            others = {n: graphed_rate(n, 32) for n in ('disentangled_simple.json', 'lstm_simple.json',
+                                                       'small_baseline.json')}
             result['batch32_configs'] = others
+            result['other_configs'] = {'lstm_simple.json': graphed_rate('lstm_simple.json', B),
+                                       'disentangled_128x128x40.json': graphed_rate('disentangled_128x128x40.json', 32)}
             # the rate of the command-line path beside the ring numbers above: one epoch of the Trainer
             try:
                 result['trainer_epoch'] = {f'batch{b}': trainer_epoch(args.config, b) for b in sorted({32, B})}
@@ -623,9 +687,14 @@ def main():
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == 'train':
         result['cpu_baseline'] = cpu_baseline(kind, cfg)
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dp:
+        os.dup2(2, 1)                         # (the teardown may print again)
         dist.barrier()
         dist.destroy_process_group()
 

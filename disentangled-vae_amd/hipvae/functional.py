@@ -3,7 +3,7 @@
 Each Function covers one fusion region of the network and runs only HIP kernels from
 libdvae_hip.so in both directions:
 
-  EncoderCNN   [Conv(k4,s2,p1) -> BN -> LeakyReLU]* -> flatten -> Linear -> LeakyReLU
+  encoder_cnn  [Conv(k4,s2,p1) -> BN -> LeakyReLU]* (EncoderConvs) -> flatten -> Linear -> LeakyReLU (EncoderFC)
   DecoderCNN   Linear -> LeakyReLU -> [ConvT -> BN -> LeakyReLU]* -> ConvT(bias) -> sigmoid
   Linear       x W^T + b (+ LeakyReLU)
   LSTMEncoder  (bi)directional multi-layer LSTM over a sequence, returns the final hidden states
@@ -174,13 +174,14 @@ def _fuse_bn_stats(channels: int) -> bool:
     return channels <= 64
 
 
-class EncoderCNN(torch.autograd.Function):
-    """CNNEncoder / LightCNNEncoder of the reference (models/encoders.py:11-97)."""
+class EncoderConvs(torch.autograd.Function):
+    """The convolution stack of CNNEncoder / LightCNNEncoder of the reference (models/encoders.py:28-39, 72-83):
+    frames [N, H, W, Cin] -> the last layer's BatchNorm + LeakyReLU output [N, h, w, C] (NHWC)."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, training: bool, bns: List[BNState], fc_w: Tensor, fc_b: Tensor, *wgb: Tensor):
-        # x: [N, H, W, Cin] NHWC; wgb = conv weights (L), then BN gammas (L), then BN betas (L)
-        _need_gpu(x, 'EncoderCNN')
+    def forward(ctx, x: Tensor, training: bool, bns: List[BNState], *wgb: Tensor):
+        # wgb = conv weights (L), then BN gammas (L), then BN betas (L)
+        _need_gpu(x, 'EncoderConvs')
         L = len(bns)
         conv_w, gammas, betas = wgb[:L], wgb[L:2 * L], wgb[2 * L:3 * L]
         ys, affs = [], []
@@ -199,42 +200,26 @@ class EncoderCNN(torch.autograd.Function):
             affs.append(aff)
             cur, sc, sh, act = y, aff[0], aff[1], ops.ACT_LRELU
         u = ops.affine_act(cur, sc, sh, ops.ACT_LRELU)
-        N, h, w, C = u.shape
-        S = h * w
-        F_out = fc_w.shape[0]
-        if fc_w.shape[1] != C * S:
-            raise RuntimeError(f"encoder fc expects {fc_w.shape[1]} inputs but the conv stack produced {C * S}")
-        # reference flattens NCHW (c,h,w); ours is (h,w,c): permute the weight columns instead
-        w_perm = ops.permute3(fc_w.detach(), (F_out, C, S), (0, 2, 1)).view(F_out, S * C)
-        u_flat = u.view(N, S * C)
-        feat = ops.gemm_nt(u_flat, w_perm, fc_b.detach(), ops.ACT_LRELU)
         if training:
-            ctx.save_for_backward(x, u_flat, w_perm, feat, *ys, *conv_w)
+            ctx.save_for_backward(x, *ys, *conv_w)
             ctx.affs = affs
             ctx.gammas = [g.detach() for g in gammas]
             ctx.L = L
-            ctx.fc_shape = (F_out, C, S)
         else:
             ctx.L = -1
-        return feat
+        return u
 
     @staticmethod
-    def backward(ctx, dfeat: Tensor):
+    def backward(ctx, du: Tensor):
         if ctx.L < 0:
-            raise RuntimeError("EncoderCNN: backward is only implemented for training mode (batch statistics)")
+            raise RuntimeError("EncoderConvs: backward is only implemented for training mode (batch statistics)")
         L = ctx.L
         saved = ctx.saved_tensors
-        x, u_flat, w_perm, feat = saved[:4]
-        ys, conv_w = saved[4:4 + L], saved[4 + L:4 + 2 * L]
+        x = saved[0]
+        ys, conv_w = saved[1:1 + L], saved[1 + L:1 + 2 * L]
         affs = ctx.affs
-        F_out, C, S = ctx.fc_shape
-        off = _OffPath(dfeat)
-        dfeat = dfeat.contiguous()
-        dpre = torch.empty_like(dfeat)                           # the incoming gradient is not ours to overwrite
-        d_fc_b = ops.bias_act_bwd(dfeat, feat, ops.ACT_LRELU, True, dst=dpre)
-        d_fc_w = off.run(lambda: ops.permute3(ops.gemm_tn(dpre, u_flat), (F_out, S, C), (0, 2, 1)).view(F_out, C * S),
-                         dpre)                                   # via [F, S*C]
-        du = ops.gemm_nn(dpre, w_perm).view(ys[-1].shape)        # grad wrt post-activation of last conv
+        du = du.contiguous()                                     # grad wrt post-activation of last conv
+        off = _OffPath(du)
         d_conv, d_gamma, d_beta = [None] * L, [None] * L, [None] * L
         parts = None                      # BatchNorm-backward statistics reduced by the producer of du
         for l in range(L - 1, -1, -1):
@@ -260,6 +245,8 @@ class EncoderCNN(torch.autograd.Function):
                 d_conv[l] = off.run(lambda dy=dy, l=l, psc=psc, psh=psh: ops.conv4s2_wgrad(
                     dy, None, None, ops.ACT_NONE, ys[l - 1], psc, psh, ops.ACT_LRELU), dy)
                 continue
+            if l == L - 1:
+                du = du.clone()                                  # the incoming gradient is not ours to overwrite
             d_gamma[l], d_beta[l] = ops.bn_bwd(du, ys[l], sc, sh, mean, invstd, ctx.gammas[l], parts)
             dy = du                                              # now dL/d(raw conv output)
             if l > 0:
@@ -274,7 +261,54 @@ class EncoderCNN(torch.autograd.Function):
             else:
                 d_conv[0] = ops.conv4s2_wgrad(dy, None, None, ops.ACT_NONE, x, None, None, ops.ACT_NONE)
         off.join()
-        return (None, None, None, d_fc_w, d_fc_b, *d_conv, *d_gamma, *d_beta)
+        return (None, None, None, *d_conv, *d_gamma, *d_beta)
+
+
+class EncoderFC(torch.autograd.Function):
+    """The Linear + LeakyReLU that follows the convolution stack (models/encoders.py:43-46, 87-90) on its NHWC
+    output: the reference flattens NCHW (c,h,w) columns, so the weight's columns are permuted to (h,w,c) on the
+    way in and its gradient back on the way out."""
+
+    @staticmethod
+    def forward(ctx, u: Tensor, fc_w: Tensor, fc_b: Tensor):
+        _need_gpu(u, 'EncoderFC')
+        N, h, w, C = u.shape
+        S = h * w
+        F_out = fc_w.shape[0]
+        if fc_w.shape[1] != C * S:
+            raise RuntimeError(f"encoder fc expects {fc_w.shape[1]} inputs but the conv stack produced {C * S}")
+        w_perm = ops.permute3(fc_w.detach(), (F_out, C, S), (0, 2, 1)).view(F_out, S * C)
+        u_flat = u.contiguous().view(N, S * C)
+        feat = ops.gemm_nt(u_flat, w_perm, fc_b.detach(), ops.ACT_LRELU)
+        ctx.save_for_backward(u_flat, w_perm, feat)
+        ctx.fc_shape = (F_out, C, S)
+        ctx.u_shape = tuple(u.shape)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat: Tensor):
+        u_flat, w_perm, feat = ctx.saved_tensors
+        F_out, C, S = ctx.fc_shape
+        off = _OffPath(dfeat)
+        dfeat = dfeat.contiguous()
+        dpre = torch.empty_like(dfeat)                           # the incoming gradient is not ours to overwrite
+        d_fc_b = ops.bias_act_bwd(dfeat, feat, ops.ACT_LRELU, True, dst=dpre)
+        d_fc_w = off.run(lambda: ops.permute3(ops.gemm_tn(dpre, u_flat), (F_out, S, C), (0, 2, 1)).view(F_out, C * S),
+                         dpre)                                   # via [F, S*C]
+        du = ops.gemm_nn(dpre, w_perm).view(ctx.u_shape) if ctx.needs_input_grad[0] else None
+        off.join()
+        return du, d_fc_w, d_fc_b
+
+
+def encoder_cnn(x: Tensor, training: bool, bns: List[BNState], fc_w: Tensor, fc_b: Tensor, *wgb: Tensor) -> Tensor:
+    """CNNEncoder / LightCNNEncoder of the reference (models/encoders.py:11-97) as two autograd nodes, with the
+    second cut of a staged data-parallel step between them: the Linear layer's weight gradient (the largest
+    gradient tensor of the encoders) is then complete, and can travel, before the convolution stack's backward
+    runs."""
+    from .parallel import stage_boundary
+    u = EncoderConvs.apply(x, training, bns, *wgb)
+    (u,) = stage_boundary(u, level=2)
+    return EncoderFC.apply(u, fc_w, fc_b)
 
 
 # =================================================================================================

@@ -163,22 +163,24 @@ def broadcast_flat(tensors, group=None, src: int = 0):
 class GraphedDataParallelStep(GraphedTrainStep):
     """The captured step for one replica of a data-parallel job (one process per GPU).
 
-    Three graphs with the gradient all-reduces between them (hipvae.parallel.StagedGrads):
-      graph A1  zero_grad + forward + loss + backward of the loss and the decoder, down to the model's
-                stage_boundary, and one multi-tensor copy of those gradients into run 0 of the flat buffer;
-      all-reduce of run 0, on the communication stream: it travels while
-      graph A2  (backward of the encoders, gradients copied into run 1) runs on the compute stream;
-      all-reduce of run 1;
-      graph B   clip + Adam reading the averaged gradients in place (p.grad are views of the flat buffer).
-    No collective is captured.  Compared with the eager path (GradSync: bucketed all-reduces launched from
-    autograd hooks) the host issues three replays and two collectives per step instead of several hundred
-    launches, which matters as soon as several ranks share a node's cores.  Semantics are GradSync's:
-    parameters and buffers broadcast from rank 0, gradients averaged before clipping, BatchNorm statistics
-    per rank."""
+    One graph per backward stage with the gradient all-reduces between them (hipvae.parallel.StagedGrads):
+      graph 1   zero_grad + forward + loss + backward of the loss and the decoder, down to the model's first
+                stage boundary, and one multi-tensor copy of those gradients into run 0 of the flat buffer;
+      all-reduce of run 0 on the communication stream: it travels while
+      graph 2   (backward of the encoders above their convolution stacks: heads, recurrences, the large Linear
+                layers; gradients copied into run 1) runs on the compute stream;
+      all-reduce of run 1, which travels while
+      graph 3   (backward of the convolution stacks, run 2) runs;
+      all-reduce of run 2 (the convolution filters: a few hundred KB, the only exposed one);
+      last      clip + Adam reading the averaged gradients in place (p.grad are views of the flat buffer).
+    A model with fewer boundaries has fewer graphs.  No collective is captured.  Compared with the eager path
+    (GradSync: bucketed all-reduces launched from autograd hooks) the host issues a handful of replays and
+    collectives per step instead of several hundred launches, which matters as soon as several ranks share a
+    node's cores.  Semantics are GradSync's: parameters and buffers broadcast from rank 0, gradients averaged before
+    clipping, BatchNorm statistics per rank."""
 
     def __init__(self, model, optimizer, loss_of, example_video, gradient_clip: float = 0.0, warmup: int = 2,
                  process_group=None, broadcast_parameters: bool = True):
-        from .parallel import StagedGrads
         if not dist.is_initialized():
             raise RuntimeError("GraphedDataParallelStep needs an initialised torch.distributed process group")
         self.group = process_group
@@ -216,23 +218,27 @@ class GraphedDataParallelStep(GraphedTrainStep):
     def _step(self):              # the eager warm-up steps: the same sequence, collectives included
         losses = self._stage1()
         self.staged.reduce(0)
-        self.staged.stage2()
-        self.staged.reduce(1)
+        for k in range(2, self.staged.nstages + 1):
+            self.staged.stage(k)
+            self.staged.reduce(k - 1)
         self._update_part()
         return losses
 
     def _capture(self):
         # thread-local capture mode: the process group's watchdog thread polls events of finished
-        # collectives while this thread captures, which the default (global) mode may refuse.  The three
+        # collectives while this thread captures, which the default (global) mode may refuse.  The
         # graphs share one memory pool and are always replayed in this order.
         torch.cuda.current_stream().wait_stream(self.staged.comm_stream)
-        self.graph = torch.cuda.CUDAGraph()
         cs = self._capture_stream
+        self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=cs, capture_error_mode='thread_local'):
             self.losses = self._stage1()
-        self.graph_stage2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_stage2, pool=self.graph.pool(), stream=cs, capture_error_mode='thread_local'):
-            self.staged.stage2()
+        self.stage_graphs = []                     # stages 2.. in order
+        for k in range(2, self.staged.nstages + 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.graph.pool(), stream=cs, capture_error_mode='thread_local'):
+                self.staged.stage(k)
+            self.stage_graphs.append(g)
         self.graph_update = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_update, pool=self.graph.pool(), stream=cs, capture_error_mode='thread_local'):
             # (finish() makes the capturing stream wait for the communication stream: outside capture)
@@ -246,8 +252,9 @@ class GraphedDataParallelStep(GraphedTrainStep):
         self._before_replay(video)
         self.graph.replay()
         self.staged.reduce(0)
-        self.graph_stage2.replay()
-        self.staged.reduce(1)
+        for k, g in enumerate(self.stage_graphs, start=1):
+            g.replay()
+            self.staged.reduce(k)
         torch.cuda.current_stream().wait_stream(self.staged.comm_stream)
         self.graph_update.replay()
         self.opt.note_replayed_step()

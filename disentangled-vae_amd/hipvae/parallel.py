@@ -158,33 +158,37 @@ class GradSync:
 
 
 # =================================================================================================
-# Backward in two stages, so that the first stage's gradients can travel while the second computes.
+# Backward in stages, so that the gradients of one stage can travel while the next computes.
 # =================================================================================================
-_BOUNDARY = None          # list of (tensors above the cut, detached leaves below it) while a staged step records
+_BOUNDARY = None          # list of (level, tensors above the cut, detached leaves below it) while a staged step records
 
 
-def stage_boundary(*tensors: torch.Tensor):
-    """Called by a model between its encoder and its decoder.  Outside a staged step (the normal case) it
-    returns its arguments.  Inside one it cuts the autograd graph there: the tensors are replaced by
-    detached leaves, backward from the loss stops at them (stage 1: loss and decoder, whose parameter
-    gradients are then complete), and StagedGrads.stage2 later continues from the cut with the leaves'
-    gradients (encoders).  Values are unchanged either way."""
+def stage_boundary(*tensors: torch.Tensor, level: int = 1):
+    """Called by a model where a staged data-parallel step may cut its backward pass: level 1 between encoder(s)
+    and decoder, level 2 inside an encoder (between its convolution stack and what follows).  Outside a staged
+    step (the normal case) it returns its arguments.  Inside one it cuts the autograd graph there: the tensors are
+    replaced by detached leaves, backward stops at them, and StagedGrads.stage(k) later continues from the cuts of
+    level k-1 with the leaves' gradients.  Values are unchanged either way."""
     if _BOUNDARY is None or not torch.is_grad_enabled():
         return tensors
     leaves = tuple(t.detach().requires_grad_(True) if t.requires_grad else t for t in tensors)
-    _BOUNDARY.append((tensors, leaves))
+    _BOUNDARY.append((level, tensors, leaves))
     return leaves
 
 
 class StagedGrads:
-    """One replica's gradients of a data-parallel step in ONE flat buffer made of two runs: the parameters
-    whose gradient is complete once backward has reached the model's stage_boundary (run 0: decoder side),
-    and the rest (run 1: encoder side).  Each run is averaged over the ranks by one all-reduce, launched on
-    a side stream as soon as the run is filled, so run 0 travels while stage 2 computes.  p.grad of every
-    parameter ends up as a view of the reduced buffer.  Which parameter belongs to which run is found on
-    the first step (it is a property of the model) and fixed afterwards; a model without a boundary has
-    everything in run 0.  The three phases are separate methods so that a caller can capture each as its
-    own graph and issue the collectives between the replays."""
+    """One replica's gradients of a data-parallel step in ONE flat buffer made of runs, one per backward stage:
+    stage 1 is backward from the loss to the model's level-1 boundary (decoder side), stage k continues from the
+    level-(k-1) cuts to the next (encoders above their convolution stacks; the convolution stacks).  Each run is
+    averaged over the ranks by one all-reduce, launched on a side stream as soon as the run is filled, so it travels
+    while the next stage computes; only the last, smallest run is exposed.  p.grad of every parameter ends up as a
+    view of the reduced buffer.  Which parameter belongs to which run is found during the first step (it is a
+    property of the model) and fixed afterwards; parameters that never receive a gradient sit in the last run as
+    zeros; a model without a boundary has everything in run 0.  The phases are separate methods so that a caller can
+    capture each as its own graph and issue the collectives between the replays.
+
+    A parameter used on both sides of a cut (tied weights) would be reduced before its gradient is complete: that
+    is detected during the first step and refused."""
 
     def __init__(self, params: List[torch.nn.Parameter], process_group=None):
         if not dist.is_initialized():
@@ -197,29 +201,46 @@ class StagedGrads:
         self.on_gpu = self.device.type == 'cuda'
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self.flat = None
-        self.runs = None              # [(lo, hi)] of the two runs in the flat buffer
-        self.order = None             # parameters in flat-buffer order
-        self.views = None
-        self._cut = None
-        self._first = None            # ids of the parameters in run 0
+        self.runs = []                # [(lo, hi)] of the runs in the flat buffer, one per stage
+        self.order = []               # parameters in flat-buffer order
+        self.views = {}
+        self.nstages = None           # known once the first forward pass has met the model's boundaries
+        self._run_of = {}             # id(parameter) -> run
+        self._cuts = {}
+        self._levels = []
+        self._laid_out = False
+        self._seen = {}               # first step only: id(parameter) -> (gradient tensor, its version) when placed
 
     # ---- layout -------------------------------------------------------------------------------
-    def _lay_out(self, first: List[torch.nn.Parameter]):
-        ids = {id(p) for p in first}
-        self._first = ids
-        self.order = [p for p in self.params if id(p) in ids] + [p for p in self.params if id(p) not in ids]
-        n0 = sum(p.numel() for p in self.order if id(p) in ids)
-        n = sum(p.numel() for p in self.order)
-        self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.device)
-        self.runs = [(0, n0), (n0, n)]
-        self.views, off = {}, 0
-        for p in self.order:
+    def _place(self, run: int, last: bool):
+        """first step: the parameters whose gradient appeared in this stage form the next run of the buffer"""
+        if self.flat is None:
+            n = sum(p.numel() for p in self.params)
+            self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.device)
+        for p in self.params:                        # a gradient that grew after its run was closed
+            seen = self._seen.get(id(p))
+            if seen is not None and (p.grad is not seen[0] or p.grad._version != seen[1]):
+                raise RuntimeError("a parameter receives gradient on both sides of a stage boundary (shared weights); "
+                                   "StagedGrads would average it before it is complete: use GradSync for this model")
+        lo = self.runs[-1][1] if self.runs else 0
+        off = lo
+        for p in self.params:
+            if id(p) in self._run_of or (p.grad is None and not last):
+                continue
+            self._run_of[id(p)] = run
+            self.order.append(p)
             self.views[id(p)] = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
+            if p.grad is not None:
+                self._seen[id(p)] = (p.grad, p.grad._version)
+        self.runs.append((lo, off))
+        if last:
+            self._laid_out = True
+            self._seen = {}
 
     def _fill(self, run: int):
         """gradients of one run into the flat buffer (one multi-tensor copy); missing ones count as zero"""
-        ps = [p for p in self.order if (id(p) in self._first) == (run == 0)]
+        ps = [p for p in self.order if self._run_of[id(p)] == run]
         have = [p for p in ps if p.grad is not None and p.grad.data_ptr() != self.views[id(p)].data_ptr()]
         for p in ps:
             if p.grad is None:
@@ -227,10 +248,15 @@ class StagedGrads:
         if have:
             torch._foreach_copy_([self.views[id(p)] for p in have], [p.grad for p in have])
 
-    # ---- the three phases -----------------------------------------------------------------------
+    def _after_stage(self, run: int):
+        if not self._laid_out:
+            self._place(run, last=run == self.nstages - 1)
+        self._fill(run)
+
+    # ---- the phases ---------------------------------------------------------------------------
     def stage1(self, total_loss_of):
         """total_loss_of() runs forward + loss and returns (whatever the caller wants back, total loss).
-        Backward from the loss down to the boundary; run 0 filled."""
+        Backward from the loss down to the first boundary; run 0 filled."""
         global _BOUNDARY
         for p in self.params:
             p.grad = None
@@ -238,25 +264,33 @@ class StagedGrads:
         try:
             result, total = total_loss_of()
         finally:
-            self._cut, _BOUNDARY = _BOUNDARY, None
+            cuts, _BOUNDARY = _BOUNDARY, None
+        self._cuts = {}
+        for level, tensors, leaves in cuts:
+            self._cuts.setdefault(level, []).append((tensors, leaves))
+        levels = sorted(self._cuts)
+        if self.nstages is None:
+            self._levels, self.nstages = levels, 1 + len(levels)
+        elif levels != self._levels:
+            raise RuntimeError(f"the model's stage boundaries changed between steps ({self._levels} -> {levels})")
         total.backward()
-        if self.flat is None:
-            self._lay_out([p for p in self.params if p.grad is not None] if self._cut else list(self.params))
-        self._fill(0)
+        self._after_stage(0)
         return result
 
-    def stage2(self):
-        """Backward from the boundary through the rest of the model; run 1 filled."""
+    def stage(self, k: int):
+        """Stage k >= 2: backward from the cuts of the (k-1)-th boundary level down to the next; run k-1 filled."""
         above, grads = [], []
-        for tensors, leaves in self._cut or []:
+        for tensors, leaves in self._cuts.pop(self._levels[k - 2], []):
             for t, leaf in zip(tensors, leaves):
                 if leaf is not t and leaf.grad is not None:
                     above.append(t)
                     grads.append(leaf.grad)
-        self._cut = None
         if above:
             torch.autograd.backward(above, grads)
-        self._fill(1)
+        self._after_stage(k - 1)
+
+    def stage2(self):
+        self.stage(2)
 
     def reduce(self, run: int):
         """Average one run over the ranks; on a GPU the collective is ordered after what the current stream
@@ -281,7 +315,7 @@ class StagedGrads:
         dist.all_reduce(buf, op=op, group=self.group)
 
     def finish(self):
-        """The compute stream waits for both collectives; every p.grad becomes its slice of the buffer."""
+        """The compute stream waits for the collectives; every p.grad becomes its slice of the buffer."""
         if self.on_gpu:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         for p in self.order:

@@ -60,7 +60,7 @@ class _ConvEncoderBase(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         ws, gs, bs, handles = _stack_tensors(self.conv)
-        return HF.EncoderCNN.apply(_frames_nhwc(x), self.training, handles, self.fc[0].weight, self.fc[0].bias,
+        return HF.encoder_cnn(_frames_nhwc(x), self.training, handles, self.fc[0].weight, self.fc[0].bias,
                                    *ws, *gs, *bs)
 
 

@@ -1,5 +1,6 @@
-"""Two data-parallel ranks on ONE GPU: the captured three-graph step (hipvae.graph.GraphedDataParallelStep:
-decoder-side backward, reduction of its gradients, encoder-side backward, reduction of the rest, update)
+"""Two data-parallel ranks on ONE GPU: the captured step (hipvae.graph.GraphedDataParallelStep: decoder-side
+backward, reduction of its gradients beside the backward of the encoders' upper parts, reduction of those beside
+the backward of the convolution stacks, reduction of the rest, update)
 against the plain statement of its semantics (broadcast from rank 0; every step: backward, all-reduce and
 average every gradient, clip, Adam), from the same initialisation and on the same per-rank batches.
 The collectives themselves run on host copies (gloo; RCCL refuses two ranks on one device): what is
@@ -102,12 +103,14 @@ def _worker(rank, world, port, out_dir):
                     t.data.copy_(_via_host(t.data, lambda h: dist.broadcast(h, src=0)))
             step = HostReducedStep(m, opt, loss_of, batches[0], gradient_clip=1.0, broadcast_parameters=False)
             trace('captured')
-            lo, hi = step.staged.runs[0]
-            assert 0 < hi < step.staged.flat.numel()                 # both runs exist: the model has a boundary
-            first = {id(p) for p in step.staged.order[:sum(1 for p in step.staged.order if id(p) in step.staged._first)]}
-            names = {id(p): n for n, p in m.named_parameters()}
-            assert all(names[i].startswith('decoder.') for i in first)
-            assert all(n.startswith('decoder.') == (id(p) in first) for n, p in m.named_parameters())
+            # three runs, three backward graphs: decoder | encoders above their convolution stacks | the stacks
+            st = step.staged
+            assert st.nstages == 3 and len(st.runs) == 3 and len(step.stage_graphs) == 2
+            assert 0 < st.runs[0][1] == st.runs[1][0] < st.runs[1][1] == st.runs[2][0] < st.runs[2][1] == st.flat.numel()
+            run_of = {n: st._run_of[id(p)] for n, p in m.named_parameters()}
+            assert all((r == 0) == n.startswith('decoder.') for n, r in run_of.items())
+            assert all((r == 2) == ('.cnn_encoder.conv.' in n) for n, r in run_of.items()), run_of
+            assert run_of['motion_encoder.cnn_encoder.fc.0.weight'] == 1
             for v in batches:
                 step(v)
         torch.cuda.synchronize()

@@ -91,10 +91,12 @@ def test_gradsync_two_ranks_gloo(tmp_path):
 
 
 class CutNet(torch.nn.Module):
-    """encoder | decoder with the boundary the models of this package call between the two"""
+    """stem | encoder | decoder with the boundaries the models of this package call: level 1 between encoders and
+    decoder, level 2 inside one encoder (below its large layer)"""
 
     def __init__(self):
         super().__init__()
+        self.stem = torch.nn.Linear(8, 8)
         self.enc = torch.nn.Linear(8, 6)
         self.enc2 = torch.nn.Linear(8, 6)
         self.dec = torch.nn.Linear(6, 4)
@@ -102,7 +104,8 @@ class CutNet(torch.nn.Module):
 
     def forward(self, x):
         from hipvae.parallel import stage_boundary
-        z, mu = torch.tanh(self.enc(x)), self.enc2(x)
+        (h,) = stage_boundary(torch.tanh(self.stem(x)), level=2)
+        z, mu = torch.tanh(self.enc(h)), self.enc2(x)
         z, mu = stage_boundary(z, mu)
         # the loss uses the latent both through the decoder and directly, like the KL / independence terms
         return self.dec(z).pow(2).sum() + 0.1 * mu.pow(2).sum() + 0.05 * (z * mu).sum()
@@ -127,12 +130,17 @@ def _staged_worker(rank, world, port, out_dir):
         staged.stage1(lambda: (None, net(x)))
         # after stage 1 the decoder's gradients are complete and nothing has reached the encoders
         assert net.dec.weight.grad is not None and net.enc.weight.grad is None and net.enc2.weight.grad is None
+        assert staged.nstages == 3
         events.append(('stage1',))
         staged.reduce(0)
-        staged.stage2()
-        assert net.enc.weight.grad is not None and net.enc2.weight.grad is not None
+        staged.stage(2)
+        assert net.enc.weight.grad is not None and net.enc2.weight.grad is not None and net.stem.weight.grad is None
         events.append(('stage2',))
         staged.reduce(1)
+        staged.stage(3)
+        assert net.stem.weight.grad is not None
+        events.append(('stage3',))
+        staged.reduce(2)
         staged.finish()
         assert all(p.grad.data_ptr() == staged.views[id(p)].data_ptr() for p in staged.params)
         states.append({k: p.grad.clone() for k, p in net.named_parameters()})
@@ -140,17 +148,38 @@ def _staged_worker(rank, world, port, out_dir):
             for p in net.parameters():
                 p -= 0.01 * p.grad
     n_dec = sum(p.numel() for p in net.dec.parameters())
+    n_enc = sum(p.numel() for p in list(net.enc.parameters()) + list(net.enc2.parameters()))
     n_all = sum(p.numel() for p in net.parameters())
-    assert events[:4] == [('stage1',), ('reduce', n_dec), ('stage2',), ('reduce', n_all - n_dec)], events[:4]
+    # the parameter that never receives a gradient travels (as zeros) with the last run
+    assert events[:6] == [('stage1',), ('reduce', n_dec), ('stage2',), ('reduce', n_enc), ('stage3',),
+                          ('reduce', n_all - n_dec - n_enc)], events[:6]
+    # a weight used on both sides of a boundary would be averaged before its gradient is complete: refused
+    class Tied(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Linear(6, 6)
+
+        def forward(self, x):
+            from hipvae.parallel import stage_boundary
+            (z,) = stage_boundary(torch.tanh(self.w(x)))
+            return self.w(z).pow(2).sum()
+    tied = Tied()
+    st2 = StagedGrads(list(tied.parameters()))
+    st2.stage1(lambda: (None, tied(torch.randn(3, 6))))
+    try:
+        st2.stage(2)
+        raise AssertionError('a shared weight across the boundary was not refused')
+    except RuntimeError as e:
+        assert 'both sides of a stage boundary' in str(e)
     torch.save({'grads': states}, os.path.join(out_dir, f'rank{rank}.pt'))
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(120)
 def test_staged_backward_two_ranks_gloo(tmp_path):
-    """hipvae.parallel.StagedGrads: backward cut at the model's stage boundary, the decoder-side run of the
-    flat buffer reduced between the two stages, the encoder-side run after the second; the averaged
-    gradients equal those of one uncut backward pass per rank, averaged."""
+    """hipvae.parallel.StagedGrads: backward cut at the model's stage boundaries (two levels: three stages), each
+    run of the flat buffer reduced as soon as its stage has filled it; the averaged gradients equal those of one
+    uncut backward pass per rank, averaged.  Also: a weight shared across a boundary is refused."""
     world = 2
     port = _free_port()
     mp.spawn(_staged_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
