@@ -31,6 +31,8 @@ extern "C" int dvae_set_mfma_precision(int precision) {
 }
 
 #define ST(s) ((hipStream_t)(s))
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // ------------------------------------------------------------------------------------------------
 // temporal mean + frame difference: one pass over the clip, 16 B per lane, T loads in flight.
@@ -1064,10 +1066,34 @@ static ColsumGeom colsum_geom(int64_t M, int64_t C) {
   return g;
 }
 
+// Geometry of the one-launch form (partial rows AND their sum in the same launch: the workgroup of a column group
+// that finishes last adds the group's partial rows): column groups of at most 128 columns, so that the adding-up
+// is a few tens of KB per group and spread over as many workgroups as there are groups, and at most 1024
+// workgroups in all.
+static ColsumGeom colsum_geom_fused(int64_t M, int64_t C) {
+  ColsumGeom g;
+  const int64_t c4 = C / 4;
+  int tx = 1;
+  while (tx < c4 && tx < 32) tx <<= 1;
+  g.tx = tx;
+  g.ty = 256 / tx;
+  g.gy = (int)ceil_div64(c4, tx);
+  int64_t gx = ceil_div64(M, (int64_t)g.ty * 8);
+  int64_t cap = CS_MAX_ROWBLOCKS / g.gy;
+  if (cap < 1) cap = 1;
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  g.gx = gx;
+  return g;
+}
+#define CS_MAX_GROUPS 1024     // column groups of one launch = arrival counters it uses
+
 extern "C" int64_t dvae_colsum_ws_floats(int64_t M, int64_t C) {
   (void)M;
-  return (int64_t)CS_MAX_ROWBLOCKS * C + 2 * C;
+  return 2 * (int64_t)CS_MAX_ROWBLOCKS * C + 2 * C;       // up to 1024 partial rows of two values per column
 }
+
+extern "C" int64_t dvae_colsum_tickets(void) { return CS_MAX_GROUPS; }
 
 // MODE 0: BN backward stats: v1 = dz, v2 = dz * xhat   (NV = 2)
 // MODE 1: bias/activation backward: dpre = dout*act'(out) written to dst (which may be du itself), v1 = dpre (NV = 1)
@@ -1075,9 +1101,14 @@ template <int MODE>
 __global__ void __launch_bounds__(256)
 colsum_kernel(const float* du, const float* __restrict__ y, const float* __restrict__ scale,
               const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
-              int act, float* __restrict__ partials, int64_t M, int64_t C, int tx, int ty, float* dst) {
+              int act, float* __restrict__ partials, int64_t M, int64_t C, int tx, int ty, float* dst,
+              unsigned* tickets, int fin, float invM, float* out0, float* out1, float* out2, float* out3) {
+  // tickets == nullptr: the partial rows are the result.  Otherwise one launch does it all: fin 0 writes the column
+  // sums to out0 (and out1 for the second value); fin 1 (MODE 0) writes the BatchNorm-backward sums and the two
+  // coefficient vectors of bn_bwd_coeffs_kernel: out0 = dbeta, out1 = dgamma, out2 = A, out3 = B.
   constexpr int NV = MODE == 0 ? 2 : 1;
   __shared__ float red[256 * 4 * NV];
+  __shared__ int s_last;
   const int cx = threadIdx.x % tx, ry = threadIdx.x / tx;
   const int64_t c4 = (int64_t)blockIdx.y * tx + cx;
   const bool col_ok = c4 * 4 < C;
@@ -1141,17 +1172,92 @@ colsum_kernel(const float* du, const float* __restrict__ y, const float* __restr
     if (NV == 2) red[(threadIdx.x * NV + 1) * 4 + k] = a2[k];
   }
   __syncthreads();
+  // the partial rows live behind a buffer descriptor: in the one-launch form they are handed to another workgroup
+  // inside the launch, so they leave as 16-byte write-through stores and are read back past the L1 (cache policy
+  // bit 4 of a raw buffer access); a plain descriptor store otherwise
+  const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(partials, 0, 0x7fffffff, 0x00020000);
+  const int aux = tickets ? 16 : 0;
   if (ry == 0 && col_ok) {
     for (int v = 0; v < NV; ++v) {
-      float s[4] = {0.f, 0.f, 0.f, 0.f};
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
       for (int j = 0; j < ty; ++j) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) s[k] += red[(((j * tx) + cx) * NV + v) * 4 + k];
       }
-      float* dst = partials + ((int64_t)blockIdx.x * NV + v) * C + c;
-      *reinterpret_cast<float4*>(dst) = make_float4(s[0], s[1], s[2], s[3]);
+      const unsigned off = (unsigned)((((int64_t)blockIdx.x * NV + v) * C + c) * 4);
+      if (aux) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), prsrc, off, 0, 16);
+      else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), prsrc, off, 0, 0);
     }
   }
+  if (tickets == nullptr) return;
+  // every storing wave drains its stores, the workgroup meets, one lane draws the group's ticket: the workgroup that
+  // draws the last one adds up the group's rows (in row order, whoever it is: the result does not depend on it)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(tickets + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old + 1u == gridDim.x;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double acc[NV][4];
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[v][k] = 0.0;
+  if (col_ok) {
+    for (int64_t p = ry; p < (int64_t)gridDim.x; p += ty) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const unsigned off = (unsigned)(((p * NV + v) * C + c) * 4);
+        const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, off, 0, 16));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[v][k] += (double)q[k];
+      }
+    }
+  }
+  double* dred = reinterpret_cast<double*>(red);           // 256 * 4 * NV floats = room for 256 * 2 * NV doubles
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+      dred[threadIdx.x * 2 + 0] = acc[v][2 * half];
+      dred[threadIdx.x * 2 + 1] = acc[v][2 * half + 1];
+      __syncthreads();
+      if (ry == 0) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int j = 0; j < ty; ++j) {
+          s0 += dred[(j * tx + cx) * 2 + 0];
+          s1 += dred[(j * tx + cx) * 2 + 1];
+        }
+        acc[v][2 * half] = s0;
+        acc[v][2 * half + 1] = s1;
+      }
+    }
+  }
+  if (ry == 0 && col_ok) {
+    if (fin == 0) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        float* o = v == 0 ? out0 : out1;
+        if (o) *reinterpret_cast<float4*>(o + c) = make_float4((float)acc[v][0], (float)acc[v][1], (float)acc[v][2], (float)acc[v][3]);
+      }
+    } else if (NV == 2) {
+      const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float db = (float)acc[0][k], dg = (float)acc[NV - 1][k];
+        out0[c + k] = db;
+        out1[c + k] = dg;
+        const float a = -scv[k] * isv[k] * (dg * invM);
+        out2[c + k] = a;
+        out3[c + k] = -scv[k] * (db * invM) - a * muv[k];
+      }
+    }
+  }
+  // the counter is back at zero for the next launch that uses it (launches that share counters are ordered on one stream)
+  if (threadIdx.x == 0) __hip_atomic_store(tickets + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // sums partials[nparts][NV][C] -> out_v[C]; optional BN-backward constants
@@ -1312,19 +1418,34 @@ static bool bn_apply_adj(int64_t C4) { return 256 % C4 == 0; }
   if (bn_apply_adj(C / 4)) DVAE_LAUNCH(bn_bwd_apply_kernel<true>, dim3(nb), __VA_ARGS__);   \
   else DVAE_LAUNCH(bn_bwd_apply_kernel<false>, dim3(nb), __VA_ARGS__)
 
+#define CS_NOFIN (unsigned*)nullptr, 0, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr
+
+static bool colsum_one_launch(const unsigned* tickets, int64_t C) {
+  return tickets != nullptr && ceil_div64(C / 4, 32) <= CS_MAX_GROUPS && (((uintptr_t)tickets) & 3) == 0;
+}
+
 extern "C" int dvae_bn_bwd_f32(float* du, const float* y, const float* scale, const float* shift, const float* mean,
                                const float* invstd, const float* gamma, float* dgamma, float* dbeta, float* ws,
-                               int64_t M, int64_t C, dvae_stream_t stream) {
+                               unsigned* tickets, int64_t M, int64_t C, dvae_stream_t stream) {
   (void)gamma;  // scale already equals gamma*invstd
   DVAE_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd: need C%%4==0 (C=%ld)", (long)C);
-  const ColsumGeom g = colsum_geom(M, C);
+  DVAE_REQUIRE(aligned16(ws) && aligned16(dbeta) && aligned16(dgamma), "bn_bwd: ws, dbeta, dgamma must be 16-byte aligned");
   DVAE_WORK(8.0 * (double)M * C, DVAE_UNIT_BYTE);                          // du and y, once each
-  DVAE_LAUNCH(colsum_kernel<0>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), (const float*)du, y, scale, shift,
-                     mean, invstd, 0, ws, M, C, g.tx, g.ty, (float*)nullptr);
-  DVAE_LAUNCH_CHECK("bn_bwd_reduce");
-  DVAE_LAUNCH(colsum_finalize_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), (const float*)ws, g.gx, 2, C,
-                     dbeta, dgamma);
-  DVAE_LAUNCH_CHECK("bn_bwd_finalize");
+  if (colsum_one_launch(tickets, C)) {
+    const ColsumGeom g = colsum_geom_fused(M, C);
+    DVAE_LAUNCH(colsum_kernel<0>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), (const float*)du, y, scale, shift,
+                       mean, invstd, 0, ws, M, C, g.tx, g.ty, (float*)nullptr, tickets, 0, 0.f, dbeta, dgamma,
+                       (float*)nullptr, (float*)nullptr);
+    DVAE_LAUNCH_CHECK("bn_bwd_reduce");
+  } else {
+    const ColsumGeom g = colsum_geom(M, C);
+    DVAE_LAUNCH(colsum_kernel<0>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), (const float*)du, y, scale, shift,
+                       mean, invstd, 0, ws, M, C, g.tx, g.ty, (float*)nullptr, CS_NOFIN);
+    DVAE_LAUNCH_CHECK("bn_bwd_reduce");
+    DVAE_LAUNCH(colsum_finalize_kernel, dim3((unsigned)C), dim3(256), 0, ST(stream), (const float*)ws, g.gx, 2, C,
+                       dbeta, dgamma);
+    DVAE_LAUNCH_CHECK("bn_bwd_finalize");
+  }
   const int64_t total4 = M * C / 4;
   DVAE_WORK(12.0 * (double)M * C, DVAE_UNIT_BYTE);                         // du, y in; dy out
   DVAE_LAUNCH_BN_APPLY(bn_apply_blocks(total4, C / 4), dim3(256), 0, ST(stream), (float4*)du, (const float4*)y,
@@ -1344,8 +1465,26 @@ extern "C" int dvae_bn_bwd_reduce_f32(const float* du, const float* y, const flo
   const ColsumGeom g = colsum_geom(M, C);
   DVAE_WORK(8.0 * (double)M * C, DVAE_UNIT_BYTE);                          // du and y, once each
   DVAE_LAUNCH(colsum_kernel<0>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), du, y,
-                     scale, shift, mean, invstd, 0, partials, M, C, g.tx, g.ty, (float*)nullptr);
+                     scale, shift, mean, invstd, 0, partials, M, C, g.tx, g.ty, (float*)nullptr, CS_NOFIN);
   DVAE_LAUNCH_CHECK("bn_bwd_reduce");
+  return 0;
+}
+
+// dvae_bn_bwd_reduce_f32 + dvae_bn_bwd_coeffs_f32 in one launch
+extern "C" int dvae_bn_bwd_reduce_coeffs_f32(const float* du, const float* y, const float* scale, const float* shift,
+                                             const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                             float* coef_a, float* coef_b, float* ws, unsigned* tickets, int64_t M,
+                                             int64_t C, dvae_stream_t stream) {
+  DVAE_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd_reduce_coeffs: need C%%4==0 (C=%ld)", (long)C);
+  DVAE_REQUIRE(du && y && scale && shift && mean && invstd && dgamma && dbeta && coef_a && coef_b && ws,
+               "bn_bwd_reduce_coeffs: null argument");
+  DVAE_REQUIRE(colsum_one_launch(tickets, C) && aligned16(ws), "bn_bwd_reduce_coeffs: needs the arrival counters (dvae_colsum_tickets() "
+               "zeroed 32-bit words) and a 16-byte aligned workspace");
+  const ColsumGeom g = colsum_geom_fused(M, C);
+  DVAE_WORK(8.0 * (double)M * C, DVAE_UNIT_BYTE);                          // du and y, once each
+  DVAE_LAUNCH(colsum_kernel<0>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), du, y, scale, shift, mean, invstd,
+                     0, ws, M, C, g.tx, g.ty, (float*)nullptr, tickets, 1, 1.f / (float)M, dbeta, dgamma, coef_a, coef_b);
+  DVAE_LAUNCH_CHECK("bn_bwd_reduce_coeffs");
   return 0;
 }
 
@@ -1368,7 +1507,7 @@ extern "C" int dvae_bn_bwd_from_partials_f32(float* du, const float* y, const fl
 }
 
 extern "C" int dvae_bias_act_bwd_to_f32(const float* dout, float* dpre, const float* out, int act, float* dbias,
-                                        float* ws, int64_t M, int64_t N, dvae_stream_t stream) {
+                                        float* ws, unsigned* tickets, int64_t M, int64_t N, dvae_stream_t stream) {
   DVAE_REQUIRE(M > 0 && N > 0 && N % 4 == 0, "bias_act_bwd: need N%%4==0 (N=%ld)", (long)N);
   DVAE_REQUIRE(act == DVAE_ACT_NONE || act == DVAE_ACT_LRELU, "bias_act_bwd: unsupported activation %d", act);
   DVAE_REQUIRE(dout && dpre, "bias_act_bwd: null gradient");
@@ -1383,14 +1522,23 @@ extern "C" int dvae_bias_act_bwd_to_f32(const float* dout, float* dpre, const fl
     const int ty = 256 / tx;
     DVAE_LAUNCH(colsum_kernel<1>, dim3(1, (unsigned)ceil_div64(c4, tx)), dim3(256), 0, ST(stream), dout, out,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act,
-                       dbias ? dbias : ws, M, N, tx, ty, dpre);
+                       dbias ? dbias : ws, M, N, tx, ty, dpre, CS_NOFIN);
+    DVAE_LAUNCH_CHECK("bias_act_bwd");
+    return 0;
+  }
+  if (dbias && colsum_one_launch(tickets, N) && aligned16(ws) && aligned16(dbias)) {
+    // partial rows and their sum in one launch
+    const ColsumGeom g = colsum_geom_fused(M, N);
+    DVAE_LAUNCH(colsum_kernel<1>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), dout, out,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, ws,
+                       M, N, g.tx, g.ty, dpre, tickets, 0, 0.f, dbias, (float*)nullptr, (float*)nullptr, (float*)nullptr);
     DVAE_LAUNCH_CHECK("bias_act_bwd");
     return 0;
   }
   const ColsumGeom g = colsum_geom(M, N);
   DVAE_LAUNCH(colsum_kernel<1>, dim3((unsigned)g.gx, g.gy), dim3(256), 0, ST(stream), dout, out,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, ws,
-                     M, N, g.tx, g.ty, dpre);
+                     M, N, g.tx, g.ty, dpre, CS_NOFIN);
   DVAE_LAUNCH_CHECK("bias_act_bwd");
   if (dbias) {
     DVAE_LAUNCH(colsum_finalize_kernel, dim3((unsigned)N), dim3(256), 0, ST(stream), (const float*)ws, g.gx, 1,
@@ -1400,9 +1548,9 @@ extern "C" int dvae_bias_act_bwd_to_f32(const float* dout, float* dpre, const fl
   return 0;
 }
 
-extern "C" int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, float* dbias, float* ws, int64_t M,
-                                     int64_t N, dvae_stream_t stream) {
-  return dvae_bias_act_bwd_to_f32(dout, dout, out, act, dbias, ws, M, N, stream);
+extern "C" int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, float* dbias, float* ws, unsigned* tickets,
+                                     int64_t M, int64_t N, dvae_stream_t stream) {
+  return dvae_bias_act_bwd_to_f32(dout, dout, out, act, dbias, ws, tickets, M, N, stream);
 }
 
 __global__ void __launch_bounds__(256)

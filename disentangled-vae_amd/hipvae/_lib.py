@@ -59,9 +59,11 @@ SIGNATURES = {
     'dvae_bn_eval_affine_f32': (I, [P, P, P, P, F, P, P, L, P]),
     'dvae_affine_act_f32': (I, [P, P, P, I, P, L, L, P]),
     'dvae_colsum_ws_floats': (L, [L, L]),
-    'dvae_bn_bwd_f32': (I, [P, P, P, P, P, P, P, P, P, P, L, L, P]),
-    'dvae_bias_act_bwd_f32': (I, [P, P, I, P, P, L, L, P]),
-    'dvae_bias_act_bwd_to_f32': (I, [P, P, P, I, P, P, L, L, P]),
+    'dvae_colsum_tickets': (L, []),
+    'dvae_bn_bwd_f32': (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, P]),
+    'dvae_bn_bwd_reduce_coeffs_f32': (I, [P, P, P, P, P, P, P, P, P, P, P, P, L, L, P]),
+    'dvae_bias_act_bwd_f32': (I, [P, P, I, P, P, P, L, L, P]),
+    'dvae_bias_act_bwd_to_f32': (I, [P, P, P, I, P, P, P, L, L, P]),
     'dvae_sigmoid_bwd_f32': (I, [P, P, P, P, P, L, P]),
     'dvae_permute3_f32': (I, [P, P, L, L, L, I, I, I, P]),
     'dvae_weighted_sum_f32': (I, [I, POINTER(c_void_p), POINTER(c_float), P, P]),

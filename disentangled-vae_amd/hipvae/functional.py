@@ -229,16 +229,18 @@ class EncoderConvs(torch.autograd.Function):
             # BatchNorm-backward pass is skipped: only the batch sums and two coefficient vectors are made.
             if l == 0 and x.shape[-1] == 1 and du.shape[-1] <= 128:
                 if parts is None:
-                    parts = ops.bn_bwd_reduce(du, ys[0], affs[0])
-                d_gamma[0], d_beta[0], ca, cb = ops.bn_bwd_coeffs(parts, affs[0], M)
+                    d_gamma[0], d_beta[0], ca, cb = ops.bn_bwd_reduce_coeffs(du, ys[0], affs[0])
+                else:
+                    d_gamma[0], d_beta[0], ca, cb = ops.bn_bwd_coeffs(parts, affs[0], M)
                 d_conv[0] = off.run(lambda du=du, ca=ca, cb=cb: ops.conv4s2_wgrad_bnp(du, ys[0], affs[0], ca, cb, x),
                                     du, ca, cb)
                 continue
             if (l > 0 and _fuse_bn_stats(ys[l - 1].shape[-1])
                     and ops.deconv4s2_bnin_supported(du, conv_w[l].shape[1])):
                 if parts is None:
-                    parts = ops.bn_bwd_reduce(du, ys[l], affs[l])
-                d_gamma[l], d_beta[l], ca, cb = ops.bn_bwd_coeffs(parts, affs[l], M)
+                    d_gamma[l], d_beta[l], ca, cb = ops.bn_bwd_reduce_coeffs(du, ys[l], affs[l])
+                else:
+                    d_gamma[l], d_beta[l], ca, cb = ops.bn_bwd_coeffs(parts, affs[l], M)
                 wpd = ctx.wpd[l]
                 du, parts, dy = ops.deconv4s2_dgrad_bnstat_bnin(du, ys[l], affs[l], ca, cb, wpd, ys[l - 1], affs[l - 1])
                 psc, psh = affs[l - 1][0], affs[l - 1][1]

@@ -82,6 +82,30 @@ def workspace(nfloats: int, device, slot: Optional[str] = None) -> Tensor:
     return buf
 
 
+_TICKETS = {}
+# DVAE_ONE_LAUNCH_SUMS=1: bias-gradient and BatchNorm-backward column sums in one launch each (the workgroup that
+# finishes last adds the partial rows inside the launch) instead of two.  Off by default: on MI355X the replayed
+# step was 0.3 % (batch 256) to 0.8 % (batch 32) SLOWER with it in a same-box A/B -- a dependent tiny kernel costs
+# about 1.6 us inside a replayed graph, less than the in-launch hand-off and the serial tail it buys.
+USE_TICKETS = os.environ.get('DVAE_ONE_LAUNCH_SUMS', '0') == '1'
+
+
+def tickets(device) -> Optional[Tensor]:
+    """The arrival counters of the one-launch reductions: zeroed 32-bit words per (device, workspace slot) that every
+    kernel using them leaves at zero again.  Launches that share them are ordered on one stream (a slot is what a
+    stream's work takes its scratch from), so they never meet."""
+    if not USE_TICKETS:
+        return None
+    slot = _WS_SLOT[-1]
+    if _STREAM_SLOT and slot == 'main':
+        slot = _STREAM_SLOT.get(torch.cuda.current_stream(device).cuda_stream, 'main')
+    key = (torch.device(device).index, slot)
+    t = _TICKETS.get(key)
+    if t is None:
+        t = _TICKETS[key] = torch.zeros(int(lib.dvae_colsum_tickets()), dtype=torch.int32, device=device)
+    return t
+
+
 # ---------------------------------------------------------------------------- split
 def split_mean_diff(video: Tensor) -> Tuple[Tensor, Tensor]:
     """video [B,T,C,H,W] -> (mean over T [B,C,H,W], frame differences [B,T-1,C,H,W])."""
@@ -347,9 +371,9 @@ def bn_bwd(du: Tensor, y: Tensor, scale, shift, mean, invstd, gamma, partials: O
                                                 _p(partials), partials.shape[0], _p(dgb[0]), _p(dgb[1]), M, C,
                                                 _stream()), 'bn_bwd_from_partials')
         return dgb[0], dgb[1]
-    ws = workspace(2 * lib.dvae_colsum_ws_floats(M, C), y.device)
+    ws = workspace(lib.dvae_colsum_ws_floats(M, C), y.device)
     check(lib.dvae_bn_bwd_f32(_p(du), _p(y), _p(scale), _p(shift), _p(mean), _p(invstd), _p(gamma), _p(dgb[0]),
-                              _p(dgb[1]), _p(ws), M, C, _stream()), 'bn_bwd')
+                              _p(dgb[1]), _p(ws), _p(tickets(y.device)), M, C, _stream()), 'bn_bwd')
     return dgb[0], dgb[1]
 
 
@@ -363,8 +387,8 @@ def bias_act_bwd(dout: Tensor, out: Optional[Tensor], act: int, want_bias: bool,
         raise RuntimeError("bias_act_bwd: dst must have dout's size")
     db = torch.empty(N, dtype=torch.float32, device=dout.device) if want_bias else None
     ws = workspace(lib.dvae_colsum_ws_floats(M, N), dout.device)
-    check(lib.dvae_bias_act_bwd_to_f32(_p(dout), _p(dout if dst is None else dst), _p(out), act, _p(db), _p(ws), M, N,
-                                       _stream()), 'bias_act_bwd')
+    check(lib.dvae_bias_act_bwd_to_f32(_p(dout), _p(dout if dst is None else dst), _p(out), act, _p(db), _p(ws),
+                                       _p(tickets(dout.device)), M, N, _stream()), 'bias_act_bwd')
     return db
 
 
@@ -563,6 +587,22 @@ def bn_bwd_coeffs(partials: Tensor, aff, M: int):
     out = torch.empty(4, C, dtype=torch.float32, device=sc.device)
     check(lib.dvae_bn_bwd_coeffs_f32(_p(partials), partials.shape[0], _p(sc), _p(mean), _p(invstd), _p(out[0]),
                                      _p(out[1]), _p(out[2]), _p(out[3]), M, C, _stream()), 'bn_bwd_coeffs')
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_bwd_reduce_coeffs(du: Tensor, y: Tensor, aff):
+    """bn_bwd_reduce + bn_bwd_coeffs in one launch: (dgamma, dbeta, A, B)."""
+    sc, sh, mean, invstd = aff
+    _chk(du, y, sc, sh, mean, invstd)
+    C = y.shape[-1]
+    M = y.numel() // C
+    if not USE_TICKETS:
+        return bn_bwd_coeffs(bn_bwd_reduce(du, y, aff), aff, M)
+    out = torch.empty(4, C, dtype=torch.float32, device=sc.device)
+    ws = workspace(lib.dvae_colsum_ws_floats(M, C), y.device)
+    check(lib.dvae_bn_bwd_reduce_coeffs_f32(_p(du), _p(y), _p(sc), _p(sh), _p(mean), _p(invstd), _p(out[0]), _p(out[1]),
+                                            _p(out[2]), _p(out[3]), _p(ws), _p(tickets(y.device)), M, C, _stream()),
+          'bn_bwd_reduce_coeffs')
     return out[0], out[1], out[2], out[3]
 
 

@@ -189,11 +189,17 @@ int dvae_affine_act_f32(const float* x, const float* scale, const float* shift, 
                         int64_t M, int64_t C, dvae_stream_t stream);
 /* Backward of BN + LeakyReLU given du = dL/d(post-activation), y = raw conv output.
  * Step 1 accumulates sum(dz) and sum(dz*xhat) per channel (dz = du*lrelu'(y*scale+shift)) and turns
- * them into dgamma, dbeta; step 2 overwrites du with dL/dy.  ws: dvae_colsum_ws_floats(M,C)*2. */
+ * them into dgamma, dbeta; step 2 overwrites du with dL/dy.  ws: dvae_colsum_ws_floats(M,C) floats.
+ * tickets (here and in the calls below that take it; NULL allowed): dvae_colsum_tickets() 32-bit words of device
+ * memory that are ZERO when the call is made and are zero again when its kernels have finished.  With them the
+ * column sums take one launch instead of two (the workgroup of a column group that finishes last adds the group's
+ * partial rows, in row order, so results do not depend on which one it is).  Calls that share the words must be
+ * ordered on one stream. */
 int64_t dvae_colsum_ws_floats(int64_t M, int64_t C);
+int64_t dvae_colsum_tickets(void);
 int dvae_bn_bwd_f32(float* du, const float* y, const float* scale, const float* shift, const float* mean,
                     const float* invstd, const float* gamma, float* dgamma, float* dbeta, float* ws,
-                    int64_t M, int64_t C, dvae_stream_t stream);
+                    unsigned* tickets, int64_t M, int64_t C, dvae_stream_t stream);
 /* The same with step 1 done elsewhere: partials[nparts][2][C] rows of (sum dz, sum dz*xhat) as written by
  * dvae_conv4s2_dgrad_bnstat_f32 / dvae_deconv4s2_dgrad_bnstat_f32 while they produced du. */
 /* Step 1's finish alone, for consumers that apply step 2 themselves as they load du (see
@@ -207,18 +213,23 @@ int64_t dvae_bn_bwd_reduce_rows(int64_t M, int64_t C);
 int dvae_bn_bwd_reduce_f32(const float* du, const float* y, const float* scale, const float* shift,
                            const float* mean, const float* invstd, float* partials, int64_t M, int64_t C,
                            dvae_stream_t stream);
+/* dvae_bn_bwd_reduce_f32 followed by dvae_bn_bwd_coeffs_f32, in one launch (tickets required). */
+int dvae_bn_bwd_reduce_coeffs_f32(const float* du, const float* y, const float* scale, const float* shift,
+                                  const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef_a,
+                                  float* coef_b, float* ws, unsigned* tickets, int64_t M, int64_t C,
+                                  dvae_stream_t stream);
 int dvae_bn_bwd_from_partials_f32(float* du, const float* y, const float* scale, const float* shift,
                                   const float* mean, const float* invstd, const float* partials, int64_t nparts,
                                   float* dgamma, float* dbeta, int64_t M, int64_t C, dvae_stream_t stream);
 /* Backward of (bias +) activation of a Linear layer: dpre = dout * act'(out) written in place over
  * dout (act NONE leaves it untouched), dbias[n] = sum_m dpre[m][n] (NULL to skip). [M,N], N%4==0. */
-int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, float* dbias, float* ws, int64_t M,
-                          int64_t N, dvae_stream_t stream);
+int dvae_bias_act_bwd_f32(float* dout, const float* out, int act, float* dbias, float* ws, unsigned* tickets,
+                          int64_t M, int64_t N, dvae_stream_t stream);
 /* The same with dpre written to its own [M,N] buffer and dout left untouched (autograd hands a node gradients it
  * must not modify: torch's LeakyReLU/Linear backward, models/encoders.py:40-43, allocate their results too);
  * dpre == dout is the in-place form above. */
 int dvae_bias_act_bwd_to_f32(const float* dout, float* dpre, const float* out, int act, float* dbias, float* ws,
-                             int64_t M, int64_t N, dvae_stream_t stream);
+                             unsigned* tickets, int64_t M, int64_t N, dvae_stream_t stream);
 /* dlogit = drecon * r * (1-r) (sigmoid backward), dbias[0] = sum(dlogit); n elements. */
 int dvae_sigmoid_bwd_f32(const float* drecon, const float* recon, float* dlogit, float* dbias, float* ws,
                          int64_t n, dvae_stream_t stream);

@@ -460,6 +460,53 @@ def test_bias_act_bwd(ops, M, N):
         assert rel_err(dst, want) < 1e-7 and rel_err(db, want.sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize('M,N', [(5120, 512), (4864, 1024), (256, 256), (5120, 4096), (1000, 36)])
+def test_column_sums_in_one_launch(ops, M, N, monkeypatch):
+    """Bias gradient and BatchNorm-backward sums as ONE launch each: the workgroup of a column group that finishes
+    last adds the group's partial rows inside the launch (hand-off through write-through stores and an arrival
+    counter).  Against fp64 sums; the same bits on every call (fixed order of the additions, whichever workgroup is
+    last) with other work keeping the chip unevenly busy in between; the counters are back at zero afterwards; and
+    the two-launch form (no counters handed in) agrees to rounding."""
+    from hipvae._lib import check, lib
+    monkeypatch.setattr(ops, 'USE_TICKETS', True)           # (not the default path: measured slower inside the step)
+    out = O.leaky_relu(rnd(M, N, seed=152))
+    dout = rnd(M, N, seed=153)
+    ref = torch.where(out > 0, dout, 0.2 * dout)
+    noise = torch.randn(4096, 4096, device='cuda')
+    side = torch.cuda.Stream()
+    results = []
+    for rep in range(4):
+        d = dev(dout)
+        torch.cuda.synchronize()
+        if rep % 2:
+            with torch.cuda.stream(side):                   # something else on the chip while the kernel runs
+                noise @ noise
+        db = ops.bias_act_bwd(d, dev(out), ops.ACT_LRELU, True)
+        results.append(db.clone())
+        assert rel_err(d, ref) < 1e-7
+    assert rel_err(results[0], ref.sum(0)) < 1e-5
+    assert all(torch.equal(results[0], r) for r in results[1:])
+    assert int(ops.tickets(torch.device('cuda', 0)).abs().sum()) == 0
+    # the two-launch form of the same entry point
+    d, db2 = dev(dout), torch.empty(N, device='cuda')
+    ws = ops.workspace(lib.dvae_colsum_ws_floats(M, N), d.device)
+    check(lib.dvae_bias_act_bwd_to_f32(d.data_ptr(), d.data_ptr(), dev(out).data_ptr(), ops.ACT_LRELU, db2.data_ptr(),
+                                       ws.data_ptr(), None, M, N, torch.cuda.current_stream().cuda_stream))
+    assert rel_err(db2, ref.sum(0)) < 1e-5 and rel_err(db2, results[0].double().cpu()) < 2e-6
+    if N % 4 == 0 and N <= 1024:
+        # BatchNorm backward: sums + coefficient vectors in one launch against the two-launch pair
+        y, gamma, beta = rnd(M, N, seed=154), rnd(N, seed=155) + 1.5, rnd(N, seed=156)
+        mu, inv = y.mean(0), 1 / torch.sqrt(y.var(0, unbiased=False) + 1e-5)
+        aff = [dev(t) for t in (gamma * inv, beta - mu * gamma * inv, mu, inv)]
+        du = dev(rnd(M, N, seed=157))
+        one = [t.clone() for t in ops.bn_bwd_reduce_coeffs(du, dev(y), aff)]
+        again = ops.bn_bwd_reduce_coeffs(du, dev(y), aff)
+        two = ops.bn_bwd_coeffs(ops.bn_bwd_reduce(du, dev(y), aff), aff, M)
+        for a, b, c in zip(one, again, two):
+            assert torch.equal(a, b) and rel_err(a, c.double().cpu()) < 5e-6
+        assert int(ops.tickets(torch.device('cuda', 0)).abs().sum()) == 0
+
+
 def test_sigmoid_bwd(ops):
     r = torch.sigmoid(rnd(3, 5, 64, 64, seed=54))
     dr = rnd(3, 5, 64, 64, seed=55)
