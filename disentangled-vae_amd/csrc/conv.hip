@@ -179,7 +179,49 @@ struct ConvArgs {
   int kt_per;
   float* ws;        // scratch the caller brought (may be nullptr) and its size
   int64_t ws_floats;
+  // bf16 storage (bf16-MFMA mode only; row-ring and single-channel kernels): which of the tensors above hold
+  // bfloat16 elements instead of floats, DVAE_ST_* bits
+  int st;
 };
+
+// Tensors that a flag of ConvArgs::st / WgradArgs::st marks are arrays of bfloat16 (same element indexing, half
+// the bytes); their pointers keep the float type of the struct and are only ever used through these helpers.
+// (DVAE_ST_X: x / P, DVAE_ST_Y: y / Q, DVAE_ST_BNY: bn_y / p_y, DVAE_ST_INY: in_y, DVAE_ST_DX: dx_out)
+// The kernels take the flags as a template argument ST, one instantiation per combination a training step
+// produces: with a run-time flag the 8-byte and the 16-byte load of one value sit on two sides of a branch and
+// write the same registers, and the compiler then orders every such load behind all loads in flight.
+__device__ __forceinline__ f32x4 unpack_bf16x4(uint2 w) {
+  f32x4 v;
+  v[0] = __uint_as_float(w.x << 16);
+  v[1] = __uint_as_float(w.x & 0xffff0000u);
+  v[2] = __uint_as_float(w.y << 16);
+  v[3] = __uint_as_float(w.y & 0xffff0000u);
+  return v;
+}
+// four consecutive elements at element offset o of a tensor stored as floats, or (b16) as bfloat16.  The load
+// hands back what memory holds (four floats, or the two dwords of four bfloat16 in [0] and [1]) and widen4s makes
+// the values of it where they are used: a conversion beside the load would wait for the load there, and the row
+// kernels issue their loads a whole row of MFMAs ahead of the use.
+__device__ __forceinline__ f32x4 ld4s(const float* base, int64_t o, bool b16) {
+  if (b16) {
+    const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + o);
+    return (f32x4){__uint_as_float(w.x), __uint_as_float(w.y), 0.f, 0.f};
+  }
+  return ldg4(base + o);
+}
+__device__ __forceinline__ f32x4 widen4s(const f32x4& raw, bool b16) {
+  return b16 ? unpack_bf16x4(make_uint2(__float_as_uint(raw[0]), __float_as_uint(raw[1]))) : raw;
+}
+__device__ __forceinline__ void st4s(float* base, int64_t o, const f32x4& v, bool b16) {
+  if (b16) {
+    uint2 w;
+    w.x = pack_bf16(v[0], v[1]);
+    w.y = pack_bf16(v[2], v[3]);
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + o) = w;
+  } else {
+    *reinterpret_cast<f32x4*>(base + o) = v;
+  }
+}
 
 // A operand of the forward implicit GEMMs.  MODE 0: conv (16 taps, input pixel 2*o-1+k);
 // MODE 1: transposed conv phase (4 taps, input pixel a+ph-th).  C1: single input channel.
@@ -481,7 +523,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
 // v_mfma_f32_16x16x4_f32, keeps the filter [Cout x 16] in registers as the A operand, and gets four
 // consecutive output channels of one pixel per lane, i.e. 16-B stores that tile each pixel's channel
 // vector.  BatchNorm partial sums are kept per lane and reduced once per workgroup.
-template <int NCB, bool BNS>
+template <int NCB, bool BNS, int ST = 0>
 __global__ void __launch_bounds__(256) conv_c1_kernel(ConvArgs g) {
   __shared__ float red[4][NCB * 16][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -516,6 +558,7 @@ __global__ void __launch_bounds__(256) conv_c1_kernel(ConvArgs g) {
   }
   const int64_t ngroups = (g.M + 15) / 16;
   const bool vec_store = (g.Cout & 3) == 0;
+  constexpr bool ybf = (ST & DVAE_ST_Y) != 0, bnybf = (ST & DVAE_ST_BNY) != 0;       // (the host sets them for vec_store shapes only)
   // two pixel groups per pass: the gathers of both are issued before either is multiplied and stored
   constexpr int U = 2;
   for (int64_t grp0 = (int64_t)blockIdx.x * 4 + wave; grp0 < ngroups; grp0 += (int64_t)gridDim.x * 4 * U) {
@@ -553,7 +596,7 @@ __global__ void __launch_bounds__(256) conv_c1_kernel(ConvArgs g) {
       if (mok && co0 < g.Cout) {
         float* dst = g.y + m * g.Cout + co0;
         if (vec_store) {
-          *reinterpret_cast<f32x4*>(dst) = acc;
+          st4s(g.y, m * g.Cout + co0, acc, ybf);
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -571,7 +614,7 @@ __global__ void __launch_bounds__(256) conv_c1_kernel(ConvArgs g) {
         float yv[4] = {0.f, 0.f, 0.f, 0.f};
         const float* yp = g.bn_y + m * g.Cout + co0;
         if (vec_store) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(yp);
+          const f32x4 t = widen4s(ld4s(g.bn_y, m * g.Cout + co0, bnybf), bnybf);
           yv[0] = t[0]; yv[1] = t[1]; yv[2] = t[2]; yv[3] = t[3];
         } else {
 #pragma unroll
@@ -672,7 +715,7 @@ __device__ __forceinline__ s16x4 bf_quad(float k0, float k1, float k2, float k3)
 // BNIN: the input is a gradient that still has to go through its own layer's BatchNorm backward
 // (x = du, in_y = that layer's raw output, dx = scale*dz + A*y + B formed on the way into LDS and
 // written to dx_out for the rows the workgroup owns), as in conv_rows_kernel.
-template <int CIN, int COUT, int WAVES_PER_EU, bool XF, bool BNS, bool BNIN, bool BF>
+template <int CIN, int COUT, int WAVES_PER_EU, bool XF, bool BNS, bool BNIN, bool BF, int ST = 0>
 __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs g) {
   typedef RowOps<BF> R;
   typedef typename R::frag frag_t;
@@ -684,6 +727,9 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
   const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6, ph = phase >> 1, pw = phase & 1;
   const int i16 = lane & 15, kq = lane >> 4;
   const int W = g.W, H = g.H;
+  static_assert(BF || ST == 0, "bf16 storage goes with bf16 MFMA operands");
+  constexpr bool xbf = (ST & DVAE_ST_X) != 0, ybf = (ST & DVAE_ST_Y) != 0, bnybf = (ST & DVAE_ST_BNY) != 0,
+                 inybf = (ST & DVAE_ST_INY) != 0, dxbf = (ST & DVAE_ST_DX) != 0;
   // component m of wa[cb][t][u] multiplies channel 16u + 4kq + m of tap t into output channel 16cb + i16
   frag_t wa[NCB][4][NU];
 #pragma unroll
@@ -744,8 +790,8 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
     for (int j = 0; j < NLD; ++j) {
       const int f = threadIdx.x + 256 * j;
       const int64_t o = off + 4 * (rok && f < row_pieces ? f : 0);
-      raw[j] = ldg4(g.x + o);
-      if (BNIN) rawy[j] = ldg4(g.in_y + o);
+      raw[j] = ld4s(g.x, o, xbf);
+      if (BNIN) rawy[j] = ld4s(g.in_y, o, inybf);
     }
   };
   auto deposit = [&](int64_t row) {          // transform and write the fetched row into its slot
@@ -755,16 +801,16 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
     for (int j = 0; j < NLD; ++j) {
       const int f = threadIdx.x + 256 * j;
       if (f < row_pieces) {
-        f32x4 v = raw[j];
+        f32x4 v = widen4s(raw[j], xbf);
         if (BNIN) {
-          const f32x4 y = rawy[j];
+          const f32x4 y = widen4s(rawy[j], inybf);
           const f32x4 z = y * sc + sh;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float dz = z[e] > 0.f ? v[e] : v[e] * LRELU_SLOPE;
             v[e] = fmaf(sc[e], dz, fmaf(ca[e], y[e], cb2[e]));
           }
-          if (owned) *reinterpret_cast<f32x4*>(g.dx_out + row * (int64_t)row_pieces * 4 + 4 * f) = v;
+          if (owned) st4s(g.dx_out, row * (int64_t)row_pieces * 4 + 4 * f, v, dxbf);
         } else if (XF) {
           const f32x4 z = v * sc + sh;       // slope <= 1: lrelu(z) = max(z, slope z)
           const f32x4 zs = z * slope;
@@ -792,7 +838,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
       f32x4 yv[NCB];
       if (BNS) {
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) yv[cb] = ldg4(g.bn_y + orow * COUT + 16 * cb + 4 * kq);
+        for (int cb = 0; cb < NCB; ++cb) yv[cb] = ld4s(g.bn_y, orow * COUT + 16 * cb + 4 * kq, bnybf);
       }
       f32x4 acc[NCB][2];
 #pragma unroll
@@ -830,17 +876,18 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
       for (int cb = 0; cb < NCB; ++cb) {
         // D: row = output channel 16cb + 4kq + r, column = pixel 16j + i16
         const f32x4 v = acc[cb][0] + acc[cb][1];
-        *reinterpret_cast<f32x4*>(g.y + orow * COUT + 16 * cb + 4 * kq) = v;
+        st4s(g.y, orow * COUT + 16 * cb + 4 * kq, v, ybf);
         if (!BNS) {
           s1[cb] += v;
           s2[cb] += v * v;
         } else {
+          const f32x4 yw = widen4s(yv[cb], bnybf);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float z = fmaf(yv[cb][e], bsc[cb][e], bsh[cb][e]);
+            const float z = fmaf(yw[e], bsc[cb][e], bsh[cb][e]);
             const float dz = z > 0.f ? v[e] : v[e] * LRELU_SLOPE;
             s1[cb][e] += dz;
-            s2[cb][e] += dz * ((yv[cb][e] - bmu[cb][e]) * bis[cb][e]);
+            s2[cb][e] += dz * ((yw[e] - bmu[cb][e]) * bis[cb][e]);
           }
         }
       }
@@ -1059,7 +1106,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows8_kernel(ConvArg
 // dvae_bn_bwd_coeffs_f32) on its way into LDS -- the elementwise BatchNorm-backward pass over the
 // tensor disappears.  The rows a workgroup owns (not its halo rows) are also written to dx_out for
 // the weight-gradient kernel.
-template <int CIN, int COUT, int WAVES_PER_EU, bool XF, bool BNS, bool BNIN, bool BF>
+template <int CIN, int COUT, int WAVES_PER_EU, bool XF, bool BNS, bool BNIN, bool BF, int ST = 0>
 __global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvArgs g) {
   typedef RowOps<BF> R;
   typedef typename R::frag frag_t;
@@ -1073,6 +1120,9 @@ __global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvA
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, kq = lane >> 4;
   const int W = g.W, H = g.H, Wo = W >> 1, Ho = H >> 1;
+  static_assert(BF || ST == 0, "bf16 storage goes with bf16 MFMA operands");
+  constexpr bool xbf = (ST & DVAE_ST_X) != 0, ybf = (ST & DVAE_ST_Y) != 0, bnybf = (ST & DVAE_ST_BNY) != 0,
+                 inybf = (ST & DVAE_ST_INY) != 0, dxbf = (ST & DVAE_ST_DX) != 0;
   const int half = Wo + 1;                          // pixels of one parity, with its zero pixel
   const int slot_floats = 2 * half * PS;
   // component m of wa[t][u] multiplies channel 16u + 4kq + m of tap t into output channel 16 wave + i16
@@ -1128,8 +1178,8 @@ __global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvA
     for (int j = 0; j < NLD; ++j) {
       const int f = threadIdx.x + NT * j;
       const int64_t o = off + 4 * (rok && f < row_pieces ? f : 0);
-      raw.v[j] = ldg4(g.x + o);
-      if (BNIN) raw.y[j] = ldg4(g.in_y + o);
+      raw.v[j] = ld4s(g.x, o, xbf);
+      if (BNIN) raw.y[j] = ld4s(g.in_y, o, inybf);
     }
   };
   auto deposit = [&](int64_t row, const Raw& raw) {   // transform, split by column parity, store
@@ -1139,16 +1189,16 @@ __global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvA
     for (int j = 0; j < NLD; ++j) {
       const int f = threadIdx.x + NT * j;
       if (f < row_pieces) {
-        f32x4 v = raw.v[j];
+        f32x4 v = widen4s(raw.v[j], xbf);
         if (BNIN) {
-          const f32x4 y = raw.y[j];
+          const f32x4 y = widen4s(raw.y[j], inybf);
           const f32x4 z = y * sc + sh;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float dz = z[e] > 0.f ? v[e] : v[e] * LRELU_SLOPE;
             v[e] = fmaf(sc[e], dz, fmaf(ca[e], y[e], cb[e]));
           }
-          if (owned) *reinterpret_cast<f32x4*>(g.dx_out + row * (int64_t)row_pieces * 4 + 4 * f) = v;
+          if (owned) st4s(g.dx_out, row * (int64_t)row_pieces * 4 + 4 * f, v, dxbf);
         } else if (XF) {
           const f32x4 z = v * sc + sh;       // slope <= 1: lrelu(z) = max(z, slope z)
           const f32x4 zs = z * slope;
@@ -1180,8 +1230,8 @@ __global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvA
     for (int j = 0; j < Wo / 16; ++j) {
       const int ob = 16 * j + i16;
       const int64_t orow = r * Wo + ob;
-      f32x4 yv;
-      if (BNS) yv = ldg4(g.bn_y + orow * COUT + 16 * wave + 4 * kq);
+      f32x4 yv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (BNS) yv = ld4s(g.bn_y, orow * COUT + 16 * wave + 4 * kq, bnybf);
       f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int kh = 0; kh < 4; ++kh) {
@@ -1211,17 +1261,18 @@ __global__ void __launch_bounds__(COUT * 4, WAVES_PER_EU) conv_rows_kernel(ConvA
       }
       // D: row = output channel 16 wave + 4kq + e, column = output pixel ob
       const f32x4 v = acc[0] + acc[1];
-      *reinterpret_cast<f32x4*>(g.y + orow * COUT + 16 * wave + 4 * kq) = v;
+      st4s(g.y, orow * COUT + 16 * wave + 4 * kq, v, ybf);
       if (!BNS) {
         s1 += v;
         s2 += v * v;
       } else {
+        const f32x4 yw = widen4s(yv, bnybf);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float z = fmaf(yv[e], bsc[e], bsh[e]);
+          const float z = fmaf(yw[e], bsc[e], bsh[e]);
           const float dz = z > 0.f ? v[e] : v[e] * LRELU_SLOPE;
           s1[e] += dz;
-          s2[e] += dz * ((yv[e] - bmu[e]) * bis[e]);
+          s2[e] += dz * ((yw[e] - bmu[e]) * bis[e]);
         }
       }
     }
@@ -1312,6 +1363,32 @@ conv_slab_reduce_kernel(const float4* __restrict__ slab, int S, int64_t n4, int 
   }
 }
 
+// The row kernels on bf16-stored tensors: one instantiation per combination that a training step produces
+// (false: none for this kernel variant and these flags).
+template <int CI, int CO, int WPE, bool XF, bool BNS, bool BNIN>
+static bool launch_deconv_rows_st(const ConvArgs& g, dim3 grid, hipStream_t stream) {
+  if constexpr (CI == 64 && CO == 32 && !BNS && !BNIN) {
+    // the decoder's last block writes its raw output as bf16
+    if (g.st == DVAE_ST_Y) {
+      DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, XF, BNS, BNIN, true, DVAE_ST_Y>), grid, dim3(256), 0, stream, g);
+      return true;
+    }
+  }
+  return false;
+}
+template <int CI, int CO, int WPE, bool XF, bool BNS, bool BNIN>
+static bool launch_conv_rows_st(const ConvArgs& g, dim3 grid, size_t lds, hipStream_t stream) {
+  if constexpr (CI == 32 && CO == 64 && BNS && BNIN) {
+    // its data gradient: bf16 du and y in, bf16 dL/dy out
+    if (g.st == (DVAE_ST_X | DVAE_ST_INY | DVAE_ST_DX)) {
+      DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, XF, BNS, BNIN, true, DVAE_ST_X | DVAE_ST_INY | DVAE_ST_DX>), grid,
+                  dim3(CO * 4), lds, stream, g);
+      return true;
+    }
+  }
+  return false;
+}
+
 template <int MODE>
 static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t stream) {
   const bool c1 = g.Cin == 1;
@@ -1355,7 +1432,12 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   typedef Tile<128, 32, 4, 1, true, true> T32;
 #define ROWS_K(CI, CO, WPE, XF_, BNS_, BNIN_)                                                            \
   {                                                                                                      \
-    if (bf) DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, XF_, BNS_, BNIN_, true>), grid, dim3(256), 0, stream, g); \
+    if (bf && g.st != 0) {                                                                               \
+      if (!launch_deconv_rows_st<CI, CO, WPE, XF_, BNS_, BNIN_>(g, grid, stream)) {                      \
+        dvae_set_error("%s: no row kernel for this combination of bf16-stored tensors (0x%x)", name, g.st); \
+        return -EINVAL;                                                                                  \
+      }                                                                                                  \
+    } else if (bf) DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, XF_, BNS_, BNIN_, true>), grid, dim3(256), 0, stream, g); \
     else DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, XF_, BNS_, BNIN_, false>), grid, dim3(256), 0, stream, g);   \
   }
 #define ROWS_LAUNCH(CI, CO, WPE, RESIDENT)                                                               \
@@ -1390,6 +1472,11 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     dvae_set_error("%s: no kernel takes a BatchNorm-backward input at this shape (see dvae_deconv4s2_bnin_supported)", name);
     return -EINVAL;
   }
+  if (MODE == 1 && g.st != 0) {
+    dvae_set_error("%s: bf16 storage is only taken by the few-channel row kernels (64 -> 32 and 32 -> 16 channels on "
+                   "frames 16 to 32 pixels wide)", name);
+    return -EINVAL;
+  }
   if (MODE == 1 && g.Cin == 128 && g.Cout == 64 && g.W == 8 && g.H >= 2 && aligned16(g.y) &&
       (!bns || aligned16(g.bn_y)) && (!g.in_scale || (aligned16(g.in_scale) && aligned16(g.in_shift)))) {
     const unsigned gx = (unsigned)(conv_parts_written(g.M, phases) / phases);
@@ -1412,7 +1499,12 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   }
 #define CROWS_K(CI, CO, WPE, XF_, BNS_, BNIN_)                                                           \
   {                                                                                                      \
-    if (bf) DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, XF_, BNS_, BNIN_, true>), grid, dim3(CO * 4), lds, stream, g); \
+    if (bf && g.st != 0) {                                                                               \
+      if (!launch_conv_rows_st<CI, CO, WPE, XF_, BNS_, BNIN_>(g, grid, lds, stream)) {                   \
+        dvae_set_error("%s: no row kernel for this combination of bf16-stored tensors (0x%x)", name, g.st); \
+        return -EINVAL;                                                                                  \
+      }                                                                                                  \
+    } else if (bf) DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, XF_, BNS_, BNIN_, true>), grid, dim3(CO * 4), lds, stream, g); \
     else DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, XF_, BNS_, BNIN_, false>), grid, dim3(CO * 4), lds, stream, g);   \
   }
 #define CONV_ROWS_LAUNCH(CI, CO, WPE, RESIDENT)                                                           \
@@ -1448,12 +1540,26 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     dvae_set_error("%s: no kernel takes a BatchNorm-backward input at this shape (see dvae_conv4s2_bnin_supported)", name);
     return -EINVAL;
   }
+  if (g.st != 0 && !(c1 && MODE == 0 && g.Cout <= 64 && g.Cout % 4 == 0 && aligned16(g.y) && (!bns || aligned16(g.bn_y)) &&
+                     (g.st & ~(DVAE_ST_Y | DVAE_ST_BNY)) == 0)) {
+    dvae_set_error("%s: bf16 storage is only taken by the few-channel row kernels and, for the output and the "
+                   "BatchNorm-backward tensor, by the single-channel-input kernel", name);
+    return -EINVAL;
+  }
   if (c1 && MODE == 0 && g.Cout <= 64 && aligned16(g.y) && (!bns || aligned16(g.bn_y))) {
     // one partial-statistics row per workgroup, as many rows as the caller sized the buffer for
     const dim3 grid((unsigned)conv_parts_written(g.M, 1));
 #define C1_LAUNCH(NCB)                                                                          \
-  DVAE_WORK(4.0 * ((double)g.M * 4 + (double)g.M * g.Cout * (bns ? 2 : 1)), DVAE_UNIT_BYTE);      \
-  if (bns) DVAE_LAUNCH((conv_c1_kernel<NCB, true>), grid, dim3(256), 0, stream, g);       \
+  DVAE_WORK(4.0 * (double)g.M * 4 + ((g.st & DVAE_ST_Y) ? 2.0 : 4.0) * (double)g.M * g.Cout +            \
+            (bns ? ((g.st & DVAE_ST_BNY) ? 2.0 : 4.0) * (double)g.M * g.Cout : 0.0), DVAE_UNIT_BYTE);     \
+  if (g.st != 0) {                                                                              \
+    if (NCB == 2 && bns && g.st == (DVAE_ST_Y | DVAE_ST_BNY))                                   \
+      DVAE_LAUNCH((conv_c1_kernel<2, true, DVAE_ST_Y | DVAE_ST_BNY>), grid, dim3(256), 0, stream, g); \
+    else {                                                                                      \
+      dvae_set_error("%s: the single-channel-input kernel takes bf16 storage for y and bn_y together, 32 channels", name); \
+      return -EINVAL;                                                                           \
+    }                                                                                           \
+  } else if (bns) DVAE_LAUNCH((conv_c1_kernel<NCB, true>), grid, dim3(256), 0, stream, g);       \
   else DVAE_LAUNCH((conv_c1_kernel<NCB, false>), grid, dim3(256), 0, stream, g);
     if (g.Cout <= 16) {
       C1_LAUNCH(1)
@@ -1548,8 +1654,9 @@ static int conv4s2_fwd_impl(const char* name, const float* x, const float* in_sc
                             const float* wp, float* y, float* stat_partials, int64_t N, int64_t H, int64_t W,
                             int64_t Cin, int64_t Cout, const BnBwdStat& bn, hipStream_t stream,
                             const BnBwdInput& bi = BnBwdInput{nullptr, nullptr, nullptr, nullptr},
-                            float* ws = nullptr, int64_t ws_floats = 0) {
+                            float* ws = nullptr, int64_t ws_floats = 0, int storage = 0) {
   DVAE_REQUIRE(N > 0 && Cout > 0, "%s: empty", name);
+  DVAE_REQUIRE(storage == 0 || dvae_mfma_precision() == DVAE_PRECISION_BF16, "%s: bf16 storage needs the bf16 MFMA mode", name);
   DVAE_REQUIRE(is_pow2(H) && is_pow2(W) && H >= 2 && W >= 2, "%s: H and W must be powers of two >= 2 (H=%ld W=%ld)", name,
                (long)H, (long)W);
   DVAE_REQUIRE(Cin == 1 || Cin % 4 == 0, "%s: Cin must be 1 or a multiple of 4 (Cin=%ld)", name, (long)Cin);
@@ -1568,7 +1675,7 @@ static int conv4s2_fwd_impl(const char* name, const float* x, const float* in_sc
   g.cin32 = Cin % 32 == 0;
   g.bn_y = bn.y; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_invstd = bn.invstd;
   g.in_y = bi.y; g.in_a = bi.a; g.in_b = bi.b; g.dx_out = bi.dx_out;
-  g.slab = nullptr; g.slab_stride = 0; g.kt_per = 0; g.ws = ws; g.ws_floats = ws_floats; g.part0 = 0;
+  g.slab = nullptr; g.slab_stride = 0; g.kt_per = 0; g.ws = ws; g.ws_floats = ws_floats; g.part0 = 0; g.st = storage;
   DVAE_REQUIRE(bi.y == nullptr || (in_scale && in_shift && bi.a && bi.b && bi.dx_out && aligned16(bi.y) &&
                                    aligned16(bi.a) && aligned16(bi.b) && aligned16(bi.dx_out)),
                "%s: a BatchNorm-backward input needs y, scale, shift, A, B and dx_out, 16-byte aligned", name);
@@ -1579,8 +1686,9 @@ static int deconv4s2_fwd_impl(const char* name, const float* x, const float* in_
                               int in_act, const float* wp, float* y, float* stat_partials, int64_t N, int64_t H,
                               int64_t W, int64_t Cin, int64_t Cout, const BnBwdStat& bn, hipStream_t stream,
                               const BnBwdInput& bi = BnBwdInput{nullptr, nullptr, nullptr, nullptr},
-                              float* ws = nullptr, int64_t ws_floats = 0) {
+                              float* ws = nullptr, int64_t ws_floats = 0, int storage = 0) {
   DVAE_REQUIRE(N > 0 && Cout > 0, "%s: empty", name);
+  DVAE_REQUIRE(storage == 0 || dvae_mfma_precision() == DVAE_PRECISION_BF16, "%s: bf16 storage needs the bf16 MFMA mode", name);
   DVAE_REQUIRE(is_pow2(H) && is_pow2(W), "%s: H and W must be powers of two (H=%ld W=%ld)", name, (long)H, (long)W);
   DVAE_REQUIRE(Cin % 4 == 0, "%s: Cin must be a multiple of 4 (Cin=%ld)", name, (long)Cin);
   DVAE_REQUIRE(aligned16(x) && aligned16(wp), "%s: x and wp must be 16-byte aligned", name);
@@ -1595,7 +1703,7 @@ static int deconv4s2_fwd_impl(const char* name, const float* x, const float* in_
   g.cin32 = Cin % 32 == 0;
   g.bn_y = bn.y; g.bn_scale = bn.scale; g.bn_shift = bn.shift; g.bn_mean = bn.mean; g.bn_invstd = bn.invstd;
   g.in_y = bi.y; g.in_a = bi.a; g.in_b = bi.b; g.dx_out = bi.dx_out;
-  g.slab = nullptr; g.slab_stride = 0; g.kt_per = 0; g.ws = ws; g.ws_floats = ws_floats; g.part0 = 0;
+  g.slab = nullptr; g.slab_stride = 0; g.kt_per = 0; g.ws = ws; g.ws_floats = ws_floats; g.part0 = 0; g.st = storage;
   DVAE_REQUIRE(bi.y == nullptr || (in_scale && in_shift && bi.a && bi.b && bi.dx_out && aligned16(bi.y) &&
                                    aligned16(bi.a) && aligned16(bi.b) && aligned16(bi.dx_out)),
                "%s: a BatchNorm-backward input needs y, scale, shift, A, B and dx_out, 16-byte aligned", name);
@@ -1636,19 +1744,21 @@ extern "C" int dvae_conv4s2_fwd_ws_f32(const float* x, const float* in_scale, co
 extern "C" int dvae_deconv4s2_fwd_ws_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
                                          const float* wp, float* y, float* stat_partials, int64_t N, int64_t H,
                                          int64_t W, int64_t Cin, int64_t Cout, float* ws, int64_t ws_floats,
-                                         dvae_stream_t stream) {
+                                         int storage, dvae_stream_t stream) {
   return deconv4s2_fwd_impl("deconv4s2_fwd", x, in_scale, in_shift, in_act, wp, y, stat_partials, N, H, W, Cin, Cout,
                             BnBwdStat{nullptr, nullptr, nullptr, nullptr, nullptr}, ST(stream),
-                            BnBwdInput{nullptr, nullptr, nullptr, nullptr}, ws, ws_floats);
+                            BnBwdInput{nullptr, nullptr, nullptr, nullptr}, ws, ws_floats, storage);
 }
 
 extern "C" int dvae_conv4s2_dgrad_bnstat_f32(const float* x, const float* wp, float* y, float* stat_partials,
                                              int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                                              const float* bn_y, const float* bn_scale, const float* bn_shift,
-                                             const float* bn_mean, const float* bn_invstd, dvae_stream_t stream) {
+                                             const float* bn_mean, const float* bn_invstd, int storage,
+                                             dvae_stream_t stream) {
   DVAE_REQUIRE(bn_y != nullptr, "conv4s2_dgrad_bnstat: bn_y is null");
   return conv4s2_fwd_impl("conv4s2_dgrad_bnstat", x, nullptr, nullptr, DVAE_ACT_NONE, wp, y, stat_partials, N, H, W,
-                          Cin, Cout, BnBwdStat{bn_y, bn_scale, bn_shift, bn_mean, bn_invstd}, ST(stream));
+                          Cin, Cout, BnBwdStat{bn_y, bn_scale, bn_shift, bn_mean, bn_invstd}, ST(stream),
+                          BnBwdInput{nullptr, nullptr, nullptr, nullptr}, nullptr, 0, storage);
 }
 
 extern "C" int dvae_conv4s2_bnin_supported(int64_t H, int64_t W, int64_t Cin, int64_t Cout) {
@@ -1661,12 +1771,13 @@ extern "C" int dvae_conv4s2_dgrad_bnstat_bnin_f32(const float* du_in, const floa
                                                   float* dx_out, const float* wp, float* y, float* stat_partials,
                                                   int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                                                   const float* bn_y, const float* bn_scale, const float* bn_shift,
-                                                  const float* bn_mean, const float* bn_invstd, dvae_stream_t stream) {
+                                                  const float* bn_mean, const float* bn_invstd, int storage,
+                                                  dvae_stream_t stream) {
   DVAE_REQUIRE(bn_y != nullptr && in_y != nullptr, "conv4s2_dgrad_bnstat_bnin: bn_y / in_y is null");
   DVAE_REQUIRE(dvae_conv4s2_bnin_supported(H, W, Cin, Cout), "conv4s2_dgrad_bnstat_bnin: unsupported shape or precision");
   return conv4s2_fwd_impl("conv4s2_dgrad_bnstat_bnin", du_in, in_scale, in_shift, DVAE_ACT_NONE, wp, y, stat_partials, N,
                           H, W, Cin, Cout, BnBwdStat{bn_y, bn_scale, bn_shift, bn_mean, bn_invstd}, ST(stream),
-                          BnBwdInput{in_y, in_a, in_b, dx_out});
+                          BnBwdInput{in_y, in_a, in_b, dx_out}, nullptr, 0, storage);
 }
 
 extern "C" int dvae_deconv4s2_dgrad_bnstat_f32(const float* x, const float* wp, float* y, float* stat_partials,
@@ -1729,6 +1840,7 @@ struct WgradArgs {
   const float* q_a;
   const float* q_b;
   float* dx_out;
+  int st;       // bf16 storage of P (DVAE_ST_X), Q (DVAE_ST_Y), p_y (DVAE_ST_BNY): see ConvArgs::st
 };
 
 // Both operands of the weight-gradient GEMM are row-contiguous tiles whose column position is
@@ -1877,12 +1989,17 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs g) {
 // from the single-channel image), accumulates [channels][taps] in registers over its whole pixel
 // range and the four waves' partials are summed through LDS once at the end.
 #define WG1_MAX_CB 8   // up to 128 channels
-template <int NCB, int U, bool BNP>
+template <int NCB, int U, bool BNP, int ST = 0>
 __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(WgradArgs g) {
   __shared__ float red[4 * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i16 = lane & 15, kq = lane >> 4;
   constexpr int ncb = NCB;
+  // P stored as bf16 with 32 channels: row i of channel block cb stands for channel 2i + cb instead of 16cb + i, so
+  // that one dword load brings a lane both of its channels (2-byte loads cost as much per element as dwords)
+  constexpr bool PAIR = (ST & DVAE_ST_X) != 0;
+  static_assert(!PAIR || (NCB == 2 && !BNP), "bf16 P: the 32-channel variant without a BatchNorm-backward P");
+  auto chan = [](int cb, int i) { return PAIR ? 2 * i + cb : cb * 16 + i; };
   const int HQ = 2 * g.Hs, WQ = 2 * g.Ws;
   const int kh = i16 >> 2, kw = i16 & 3;       // this lane's tap as a B-operand column
   f32x4 acc[NCB];
@@ -1891,7 +2008,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(WgradArgs g) {
   float psc[NCB], psh[NCB], pca[NCB], pcb[NCB];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
-    const int c = cb * 16 + i16;
+    const int c = chan(cb, i16);
     const bool ok = cb < ncb && c < g.C1 && g.p_scale != nullptr;
     psc[cb] = ok ? g.p_scale[c] : 1.f;
     psh[cb] = ok ? g.p_shift[c] : 0.f;
@@ -1915,14 +2032,18 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(WgradArgs g) {
         const int hi = 2 * a - 1 + kh, wi = 2 * b - 1 + kw;
         if (hi >= 0 && hi < HQ && wi >= 0 && wi < WQ) qv[u] = g.Q[(n * HQ + hi) * WQ + wi];
       }
+      if constexpr (PAIR) {
+        pv[u][0] = mok ? __uint_as_float(reinterpret_cast<const unsigned*>(g.P)[m * 16 + i16]) : 0.f;   // (C1 == 32)
+      } else {
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        pv[u][cb] = 0.f;
-        if (cb < ncb) {
-          const int c = cb * 16 + i16;
-          if (mok && c < g.C1) {
-            pv[u][cb] = g.P[m * g.C1 + c];
-            if (BNP) yv[u][cb] = g.p_y[m * g.C1 + c];
+        for (int cb = 0; cb < NCB; ++cb) {
+          pv[u][cb] = 0.f;
+          if (cb < ncb) {
+            const int c = cb * 16 + i16;
+            if (mok && c < g.C1) {
+              pv[u][cb] = g.P[m * g.C1 + c];
+              if (BNP) yv[u][cb] = g.p_y[m * g.C1 + c];
+            }
           }
         }
       }
@@ -1934,8 +2055,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(WgradArgs g) {
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
         if (cb < ncb) {
-          float v = pv[u][cb];
-          if (mok && cb * 16 + i16 < g.C1) {
+          float v = PAIR ? __uint_as_float(cb == 0 ? __float_as_uint(pv[u][0]) << 16 : __float_as_uint(pv[u][0]) & 0xffff0000u)
+                         : pv[u][cb];
+          if (mok && chan(cb, i16) < g.C1) {
             if (BNP) {
               const float y = yv[u][cb], zz = fmaf(y, psc[cb], psh[cb]);
               const float dz = zz > 0.f ? v : v * LRELU_SLOPE;
@@ -1961,7 +2083,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(WgradArgs g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[(wave * 16 + kq * 4 + r) * 16 + i16] = acc[cb][r];
       __syncthreads();
-      const int c = cb * 16 + (threadIdx.x >> 4), tap = threadIdx.x & 15;
+      const int c = chan(cb, threadIdx.x >> 4), tap = threadIdx.x & 15;
       if (c < g.C1) {
         float s = 0.f;
 #pragma unroll
@@ -2021,7 +2143,7 @@ static int wgrad_reduce_runs(int split, int64_t total) {
 // right of every Q row stand for the frame's edges, and taps above/below the frame are skipped.  Wave
 // w owns the sixteen rows 16 (w % NRB) of the gradient and an equal share of the taps.  Each workgroup
 // writes its partial gradient as one slab for wgrad_reduce_kernel.
-template <int C1, int C2, int WAVES_PER_EU, bool XP, bool XQ, bool BF>
+template <int C1, int C2, int WAVES_PER_EU, bool XP, bool XQ, bool BF, int ST = 0>
 __global__ void __launch_bounds__(256, WAVES_PER_EU) wgrad_rows_kernel(WgradArgs g) {
   constexpr int NRB = C1 / 16;            // row blocks of the gradient
   constexpr int CPARTS = 4 / NRB;         // the taps are shared between this many waves per row block
@@ -2079,13 +2201,15 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) wgrad_rows_kernel(WgradArgs
     for (int e = 0; e < 4; ++e) v[e] = fmaxf(z[e], zs[e]);
     return v;
   };
+  static_assert(BF || ST == 0, "bf16 storage goes with bf16 MFMA operands");
+  constexpr bool pbf = (ST & DVAE_ST_X) != 0, qbf = (ST & DVAE_ST_Y) != 0;
   auto fetch_p = [&](int64_t row, f32x4 (&raw)[NLP]) {
     const bool rok = row >= 0 && row < rows;
-    const float* src = g.P + (rok ? row : 0) * (int64_t)p_pieces * 4;
+    const int64_t src = (rok ? row : 0) * (int64_t)p_pieces * 4;
 #pragma unroll
     for (int j = 0; j < NLP; ++j) {
       const int f = threadIdx.x + 256 * j;
-      raw[j] = ldg4(src + 4 * (rok && f < p_pieces ? f : 0));
+      raw[j] = ld4s(g.P, src + 4 * (rok && f < p_pieces ? f : 0), pbf);
     }
   };
   auto deposit_p = [&](int64_t row, const f32x4 (&raw)[NLP]) {
@@ -2094,18 +2218,19 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) wgrad_rows_kernel(WgradArgs
     for (int j = 0; j < NLP; ++j) {
       const int f = threadIdx.x + 256 * j;
       if (f < p_pieces) {
-        const f32x4 v = XP ? transform(raw[j], psc, psh, pslope) : raw[j];
+        const f32x4 w = widen4s(raw[j], pbf);
+        const f32x4 v = XP ? transform(w, psc, psh, pslope) : w;
         *reinterpret_cast<f32x4*>(dst + (f / P4) * PSP + 4 * lp4) = v;
       }
     }
   };
   auto fetch_q = [&](int64_t row, f32x4 (&raw)[NLQ]) {
     const bool rok = row >= 0 && row < qrows;
-    const float* src = g.Q + (rok ? row : 0) * (int64_t)q_pieces * 4;
+    const int64_t src = (rok ? row : 0) * (int64_t)q_pieces * 4;
 #pragma unroll
     for (int j = 0; j < NLQ; ++j) {
       const int f = threadIdx.x + 256 * j;
-      raw[j] = ldg4(src + 4 * (rok && f < q_pieces ? f : 0));
+      raw[j] = ld4s(g.Q, src + 4 * (rok && f < q_pieces ? f : 0), qbf);
     }
   };
   auto deposit_q = [&](int64_t row, const f32x4 (&raw)[NLQ]) {
@@ -2114,7 +2239,8 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) wgrad_rows_kernel(WgradArgs
     for (int j = 0; j < NLQ; ++j) {
       const int f = threadIdx.x + 256 * j;
       if (f < q_pieces) {
-        const f32x4 v = XQ ? transform(raw[j], qsc, qsh, qslope) : raw[j];
+        const f32x4 w = widen4s(raw[j], qbf);
+        const f32x4 v = XQ ? transform(w, qsc, qsh, qslope) : w;
         float* d = dst + (1 + f / Q4) * PSQ + 4 * lq4;       // 8-byte aligned (PSQ is even)
         *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
         *reinterpret_cast<float2*>(d + 2) = make_float2(v[2], v[3]);
@@ -2596,7 +2722,7 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
                               float* dw, float* ws, int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2,
                               const float* p_y, const float* p_a, const float* p_b, dvae_stream_t stream,
                               const float* q_y = nullptr, const float* q_a = nullptr, const float* q_b = nullptr,
-                              float* dx_out = nullptr) {
+                              float* dx_out = nullptr, int storage = 0) {
   DVAE_REQUIRE(N > 0 && C1 > 0 && C2 > 0, "conv4s2_wgrad: empty");
   DVAE_REQUIRE(is_pow2(Hs) && is_pow2(Ws), "conv4s2_wgrad: Hs and Ws must be powers of two");
   DVAE_REQUIRE(C1 % 4 == 0, "conv4s2_wgrad: C1 must be a multiple of 4 (C1=%ld)", (long)C1);
@@ -2612,13 +2738,17 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
   g.slab = ws; g.Mtot = N * Hs * Ws; g.Hs = (int)Hs; g.Ws = (int)Ws; g.lh = ilog2(Hs); g.lw = ilog2(Ws);
   g.C1 = (int)C1; g.C2 = (int)C2; g.NC = (int)(16 * C2);
   g.p_y = p_y; g.p_a = p_a; g.p_b = p_b;
-  g.q_y = q_y; g.q_a = q_a; g.q_b = q_b; g.dx_out = dx_out;
+  g.q_y = q_y; g.q_a = q_a; g.q_b = q_b; g.dx_out = dx_out; g.st = storage;
   DVAE_REQUIRE(p_y == nullptr || (C2 == 1 && p_scale && p_shift && p_a && p_b),
                "conv4s2_wgrad: a BatchNorm-backward P needs a single-channel Q and scale, shift, A, B");
   const WgradPlan p = wgrad_plan(g.Mtot, Ws, C1, C2, Hs);
   g.ktiles_per_split = p.ktiles_per_split;
   hipStream_t s = ST(stream);
   const bool wbf = dvae_mfma_precision() == DVAE_PRECISION_BF16;
+  DVAE_REQUIRE(storage == 0 || (wbf && ((p.bm == -1 && storage == DVAE_ST_Y) ||
+                                        (p.bm == 0 && storage == DVAE_ST_X && C1 == 32 && g.p_y == nullptr))),
+               "conv4s2_wgrad: bf16 storage needs the bf16 MFMA mode and is only taken by the 64 x 32 row kernel (Q) "
+               "and the single-channel-Q kernel with 32 channels (P)");
   // a row-ring kernel in the variant of the current MFMA precision
 #define WG_BF(NAME, LDS, ...)                                                                           \
   {                                                                                                     \
@@ -2629,7 +2759,7 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
                                   aligned16(q_a) && aligned16(q_b) && aligned16(dx_out)),
                "conv4s2_wgrad: a BatchNorm-backward Q is only taken where dvae_conv4s2_wgrad_bnq_supported says so, "
                "with y, scale, shift, A, B and dx_out, 16-byte aligned");
-  if (C2 == 1) DVAE_WORK(4.0 * ((double)g.Mtot * C1 + (double)g.Mtot * 4), DVAE_UNIT_BYTE);       // streams P (and Q) once
+  if (C2 == 1) DVAE_WORK(((storage & DVAE_ST_X) ? 2.0 : 4.0) * (double)g.Mtot * C1 + 4.0 * (double)g.Mtot * 4, DVAE_UNIT_BYTE);       // streams P (and Q) once
   else DVAE_WORK(2.0 * (double)g.Mtot * C1 * 16 * C2, DVAE_UNIT_FLOP);
   if (p.bm == -3) {
     DVAE_REQUIRE((!p_scale || (aligned16(p_scale) && aligned16(p_shift))) && (!q_scale || (aligned16(q_scale) && aligned16(q_shift))),
@@ -2661,7 +2791,14 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
 #define WGR_LAUNCH(A, B)                                                                                  \
   {                                                                                                       \
     const size_t ldsb = (size_t)(4 * Ws * (A + 4) + 8 * (2 * Ws + 2) * (B + 2)) * sizeof(float);          \
-    if (xp && xq) WG_BF(wgrad_rows_kernel, ldsb, A, B, 2, true, true) \
+    if (g.st != 0) {                                                                                      \
+      if (A == 64 && wbf && xp && !xq && g.st == DVAE_ST_Y)                                               \
+        DVAE_LAUNCH((wgrad_rows_kernel<64, 32, 2, true, false, true, DVAE_ST_Y>), grid, dim3(256), ldsb, s, g); \
+      else {                                                                                              \
+        dvae_set_error("conv4s2_wgrad: the 64 x 32 row kernel takes a bf16 Q (with a transformed P) in bf16 mode"); \
+        return -EINVAL;                                                                                   \
+      }                                                                                                   \
+    } else if (xp && xq) WG_BF(wgrad_rows_kernel, ldsb, A, B, 2, true, true) \
     else if (xp) WG_BF(wgrad_rows_kernel, ldsb, A, B, 2, true, false) \
     else if (xq) WG_BF(wgrad_rows_kernel, ldsb, A, B, 2, false, true) \
     else WG_BF(wgrad_rows_kernel, ldsb, A, B, 2, false, false) \
@@ -2677,7 +2814,9 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
       else if (ncb <= 2) DVAE_LAUNCH((conv_wgrad_c1_kernel<2, 4, true>), grid, dim3(256), 0, s, g);
       else if (ncb <= 4) DVAE_LAUNCH((conv_wgrad_c1_kernel<4, 2, true>), grid, dim3(256), 0, s, g);
       else DVAE_LAUNCH((conv_wgrad_c1_kernel<8, 1, true>), grid, dim3(256), 0, s, g);
-    } else if (ncb <= 1) DVAE_LAUNCH((conv_wgrad_c1_kernel<1, 8, false>), grid, dim3(256), 0, s, g);
+    } else if (g.st != 0)
+      DVAE_LAUNCH((conv_wgrad_c1_kernel<2, 8, false, DVAE_ST_X>), grid, dim3(256), 0, s, g);      // (C1 == 32, checked above)
+    else if (ncb <= 1) DVAE_LAUNCH((conv_wgrad_c1_kernel<1, 8, false>), grid, dim3(256), 0, s, g);
     else if (ncb <= 2) DVAE_LAUNCH((conv_wgrad_c1_kernel<2, 8, false>), grid, dim3(256), 0, s, g);
     else if (ncb <= 4) DVAE_LAUNCH((conv_wgrad_c1_kernel<4, 4, false>), grid, dim3(256), 0, s, g);
     else DVAE_LAUNCH((conv_wgrad_c1_kernel<8, 2, false>), grid, dim3(256), 0, s, g);
@@ -2723,9 +2862,9 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
 extern "C" int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, const float* p_shift, int p_act,
                                       const float* Q, const float* q_scale, const float* q_shift, int q_act,
                                       float* dw, float* ws, int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2,
-                                      dvae_stream_t stream) {
+                                      int storage, dvae_stream_t stream) {
   return conv4s2_wgrad_impl(P, p_scale, p_shift, p_act, Q, q_scale, q_shift, q_act, dw, ws, N, Hs, Ws, C1, C2, nullptr,
-                            nullptr, nullptr, stream);
+                            nullptr, nullptr, stream, nullptr, nullptr, nullptr, nullptr, storage);
 }
 
 extern "C" int dvae_conv4s2_wgrad_bnq_supported(int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2) {
@@ -2851,7 +2990,7 @@ __global__ void __launch_bounds__(256) deconv_final_kernel(DeconvFinalArgs g) {
 
 // The same kernel for a channel count known at compile time (Cin = 16 NCB): the tap weights take 4 NCB
 // registers instead of 64, and a wave keeps the loads of U pixel blocks in flight at once.
-template <int NCB, int U>
+template <int NCB, int U, bool XB = false>
 __global__ void __launch_bounds__(256) deconv_final_fixed_kernel(DeconvFinalArgs g) {
   extern __shared__ __attribute__((aligned(16))) float contrib[];   // [(R+2)*W pixels][16 taps]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2873,7 +3012,7 @@ __global__ void __launch_bounds__(256) deconv_final_fixed_kernel(DeconvFinalArgs
   const int rows_in = g.R + 2;                   // halo row above and below
   const int nblk = (rows_in * W + 15) / 16;
   for (int blk0 = wave; blk0 < nblk; blk0 += 4 * U) {
-    float4 v[U][NCB];
+    f32x4 v[U][NCB];
     bool ok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -2881,9 +3020,9 @@ __global__ void __launch_bounds__(256) deconv_final_fixed_kernel(DeconvFinalArgs
       const int ar = p >> g.lw, b = p & (W - 1);
       const int a = a0 - 1 + ar;
       ok[u] = ar < rows_in && a >= 0 && a < H;
-      const float* px = g.x + ((n * H + (ok[u] ? a : 0)) * W + b) * (NCB * 16) + 4 * q;
+      const int64_t px = ((n * H + (ok[u] ? a : 0)) * W + b) * (NCB * 16) + 4 * q;
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) v[u][cb] = *reinterpret_cast<const float4*>(px + cb * 16);
+      for (int cb = 0; cb < NCB; ++cb) v[u][cb] = ld4s(g.x, px + cb * 16, XB);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -2891,7 +3030,8 @@ __global__ void __launch_bounds__(256) deconv_final_fixed_kernel(DeconvFinalArgs
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
-        float4 t = v[u][cb];
+        const f32x4 t4 = widen4s(v[u][cb], XB);
+        float4 t = make_float4(t4[0], t4[1], t4[2], t4[3]);
         if (g.in_scale) {
           t.x = fmaf(t.x, sc[cb].x, sh[cb].x); t.y = fmaf(t.y, sc[cb].y, sh[cb].y);
           t.z = fmaf(t.z, sc[cb].z, sh[cb].z); t.w = fmaf(t.w, sc[cb].w, sh[cb].w);
@@ -2936,8 +3076,11 @@ __global__ void __launch_bounds__(256) deconv_final_fixed_kernel(DeconvFinalArgs
 
 extern "C" int dvae_deconv4s2_final_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
                                             const float* w, const float* bias, int out_act, float* y, int64_t N,
-                                            int64_t H, int64_t W, int64_t Cin, dvae_stream_t stream) {
+                                            int64_t H, int64_t W, int64_t Cin, int storage, dvae_stream_t stream) {
   DVAE_REQUIRE(N > 0, "deconv4s2_final_fwd: empty");
+  DVAE_REQUIRE(storage == 0 || (storage == DVAE_ST_X && Cin == 32 &&
+                                (in_scale == nullptr || (aligned16(in_scale) && aligned16(in_shift)))),
+               "deconv4s2_final_fwd: bf16 storage is taken for the input, with 32 channels");
   DVAE_REQUIRE(is_pow2(H) && is_pow2(W), "deconv4s2_final_fwd: H and W must be powers of two");
   DVAE_REQUIRE(Cin % 4 == 0 && Cin <= 16 * DF_MAX_CB, "deconv4s2_final_fwd: Cin must be a multiple of 4, at most %d (Cin=%ld)",
                16 * DF_MAX_CB, (long)Cin);
@@ -2950,8 +3093,10 @@ extern "C" int dvae_deconv4s2_final_fwd_f32(const float* x, const float* in_scal
   g.bands = (int)(H / g.R);
   const size_t lds = (size_t)(g.R + 2) * W * 16 * 4;
   const bool vec_affine = in_scale == nullptr || (aligned16(in_scale) && aligned16(in_shift));
-  DVAE_WORK(4.0 * ((double)N * H * W * Cin + (double)N * 4 * H * W), DVAE_UNIT_BYTE);      // read x, write y
-  if (Cin == 32 && vec_affine)
+  DVAE_WORK((storage ? 2.0 : 4.0) * (double)N * H * W * Cin + 4.0 * (double)N * 4 * H * W, DVAE_UNIT_BYTE);   // read x, write y
+  if (Cin == 32 && vec_affine && storage)
+    DVAE_LAUNCH((deconv_final_fixed_kernel<2, 4, true>), dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);
+  else if (Cin == 32 && vec_affine)
     DVAE_LAUNCH((deconv_final_fixed_kernel<2, 4>), dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);
   else if (Cin == 64 && vec_affine)
     DVAE_LAUNCH((deconv_final_fixed_kernel<4, 2>), dim3((unsigned)(N * g.bands)), dim3(256), lds, ST(stream), g);

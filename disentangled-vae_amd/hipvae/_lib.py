@@ -80,8 +80,8 @@ SIGNATURES = {
     'dvae_deconv4s2_fwd_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P]),
     'dvae_conv_fwd_ws_floats': (L, [I, L, L, L, L, L]),
     'dvae_conv4s2_fwd_ws_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P, L, P]),
-    'dvae_deconv4s2_fwd_ws_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P, L, P]),
-    'dvae_conv4s2_dgrad_bnstat_f32': (I, [P, P, P, P, L, L, L, L, L, P, P, P, P, P, P]),
+    'dvae_deconv4s2_fwd_ws_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P, L, I, P]),
+    'dvae_conv4s2_dgrad_bnstat_f32': (I, [P, P, P, P, L, L, L, L, L, P, P, P, P, P, I, P]),
     'dvae_deconv4s2_dgrad_bnstat_f32': (I, [P, P, P, P, L, L, L, L, L, P, P, P, P, P, P]),
     'dvae_bn_bwd_from_partials_f32': (I, [P, P, P, P, P, P, P, L, P, P, L, L, P]),
     'dvae_bn_bwd_coeffs_f32': (I, [P, L, P, P, P, P, P, P, P, L, L, P]),
@@ -93,10 +93,10 @@ SIGNATURES = {
     'dvae_conv4s2_wgrad_bnq_supported': (I, [L, L, L, L, L]),
     'dvae_conv4s2_wgrad_bnq_f32': (I, [P, P, P, I, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P]),
     'dvae_conv4s2_bnin_supported': (I, [L, L, L, L]),
-    'dvae_conv4s2_dgrad_bnstat_bnin_f32': (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P, P, P, P, P, P]),
+    'dvae_conv4s2_dgrad_bnstat_bnin_f32': (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P, P, P, P, P, I, P]),
     'dvae_conv_wgrad_ws_floats': (L, [L, L, L, L, L]),
-    'dvae_conv4s2_wgrad_f32': (I, [P, P, P, I, P, P, P, I, P, P, L, L, L, L, L, P]),
-    'dvae_deconv4s2_final_fwd_f32': (I, [P, P, P, I, P, P, I, P, L, L, L, L, P]),
+    'dvae_conv4s2_wgrad_f32': (I, [P, P, P, I, P, P, P, I, P, P, L, L, L, L, L, I, P]),
+    'dvae_deconv4s2_final_fwd_f32': (I, [P, P, P, I, P, P, I, P, L, L, L, L, I, P]),
     'dvae_lstm_step_fwd_f32': (I, [P, L, P, L, P, L, P, L, P, L, P, P, P, P, P, L, P, L, L, L, P]),
     'dvae_lstm_step_bwd_pointwise_f32': (I, [P, L, P, L, P, P, L, P, L, P, P, L, L, L, P]),
     'dvae_skinny_gemm_nt_f32': (I, [P, L, P, L, P, L, L, L, L, I, P]),

@@ -382,8 +382,15 @@ class DecoderCNN(torch.autograd.Function):
         packs = ops.pack_many([(w.detach(), True) for w in dec_w]
                               + ([(w.detach(), False) for w in dec_w] if need_bwd else []))   # as in EncoderCNN
         ctx.wp = packs[L:]
+        # bf16 mode: the last block's raw output (64 -> 32 channels, the largest tensor of the step, read four times
+        # more) and the two gradients shaped like it are kept in HBM as bfloat16 where every kernel around them
+        # takes that: the 64 -> 32 row kernel with 16-wide input, then the fixed 32-channel final layer
+        st16 = (need_bwd and ops.bf16_storage() and L >= 2 and tuple(dec_w[-1].shape[:2]) == (64, 32)
+                and 4 * 2 ** (L - 1) == 16 and replicas == 1
+                and bool(ops.lib.dvae_conv4s2_bnin_supported(32, 32, 32, 64)))   # (backward's route for this block)
+        ctx.st16 = st16
         for l in range(L):
-            y, stats, nparts = ops.deconv4s2_fwd(cur, sc, sh, act, packs[l], training)
+            y, stats, nparts = ops.deconv4s2_fwd(cur, sc, sh, act, packs[l], training, out_bf16=st16 and l == L - 1)
             M = y.numel() // y.shape[-1]
             aff = _bn_affine(stats, nparts, M, gammas[l].detach(), betas[l].detach(), bns[l], training, replicas)
             ys.append(y)
@@ -438,7 +445,7 @@ class DecoderCNN(torch.autograd.Function):
         # data-gradient kernel also reduces the BatchNorm-backward statistics of the layer below it
         parts = None
         if L > 0 and _fuse_bn_stats(ys[-1].shape[-1]):
-            du, parts = ops.conv4s2_dgrad_bnstat(dlogit4, final_w.contiguous(), ys[-1], affs[-1])
+            du, parts = ops.conv4s2_dgrad_bnstat(dlogit4, final_w.contiguous(), ys[-1], affs[-1], out_bf16=ctx.st16)
         else:
             du, _, _ = ops.conv4s2_fwd(dlogit4, None, None, ops.ACT_NONE, final_w.contiguous(), False)
         d_dec, d_gamma, d_beta = [None] * L, [None] * L, [None] * L

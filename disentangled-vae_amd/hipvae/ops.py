@@ -36,6 +36,29 @@ def _p(t: Optional[Tensor]):
     return None if t is None else t.data_ptr()
 
 
+# bf16 storage of the large few-channel activations / gradients of the decoder (bf16-MFMA mode only; the flags of
+# include/dvae_hip.h).  DVAE_BF16_STORAGE=0 keeps every tensor fp32.
+ST_X, ST_Y, ST_BNY, ST_INY, ST_DX = 1, 2, 4, 8, 16
+USE_BF16_STORAGE = os.environ.get('DVAE_BF16_STORAGE', '1') != '0'
+
+
+def bf16_storage() -> bool:
+    return USE_BF16_STORAGE and lib.dvae_get_mfma_precision() == 1
+
+
+def _chk_st(*ts: Optional[Tensor]):
+    """like _chk, for tensors that may be stored as bfloat16"""
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype not in (torch.float32, torch.bfloat16) or not t.is_contiguous():
+            raise RuntimeError("hipvae ops need contiguous fp32 (or, where the kernel takes it, bf16) tensors on the GPU")
+
+
+def _st(flag: int, t: Optional[Tensor]) -> int:
+    return flag if t is not None and t.dtype == torch.bfloat16 else 0
+
+
 _WS = {}
 _WS_RETIRED = []
 _WS_SLOT = ['main']
@@ -546,35 +569,39 @@ def conv4s2_fwd(x: Tensor, scale, shift, act: int, wp: Tensor, want_stats: bool)
     return y, stats, nparts
 
 
-def deconv4s2_fwd(x: Tensor, scale, shift, act: int, wp: Tensor, want_stats: bool):
-    """x [N,H,W,Cin] -> (y [N,2H,2W,Cout], stat partials or None, number of partial rows)."""
-    _chk(x, scale, shift, wp)
+def deconv4s2_fwd(x: Tensor, scale, shift, act: int, wp: Tensor, want_stats: bool, out_bf16: bool = False):
+    """x [N,H,W,Cin] -> (y [N,2H,2W,Cout], stat partials or None, number of partial rows).  out_bf16: y is stored
+    as bfloat16 (few-channel row kernels in bf16 mode; the statistics still come from the fp32 accumulators)."""
+    _chk(scale, shift, wp)
+    _chk_st(x)
     N, H, W, Cin = x.shape
     Cout = wp.shape[1]
-    y = torch.empty(N, 2 * H, 2 * W, Cout, dtype=torch.float32, device=x.device)
+    y = torch.empty(N, 2 * H, 2 * W, Cout, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     nparts = lib.dvae_conv_stat_parts_written(N * H * W, 4)
     stats = torch.empty(nparts, 2, Cout, dtype=torch.float32, device=x.device) if want_stats else None
     need = lib.dvae_conv_fwd_ws_floats(1, N, H, W, Cin, Cout)
     ws = workspace(need, x.device) if need else None
     check(lib.dvae_deconv4s2_fwd_ws_f32(_p(x), _p(scale), _p(shift), act, _p(wp), _p(y), _p(stats), N, H, W, Cin,
-                                        Cout, _p(ws), need, _stream()), 'deconv4s2_fwd')
+                                        Cout, _p(ws), need, _st(ST_X, x) | _st(ST_Y, y), _stream()), 'deconv4s2_fwd')
     return y, stats, nparts
 
 
-def conv4s2_dgrad_bnstat(x: Tensor, wp: Tensor, bn_y: Tensor, bn_aff):
+def conv4s2_dgrad_bnstat(x: Tensor, wp: Tensor, bn_y: Tensor, bn_aff, out_bf16: bool = False):
     """conv4s2_fwd used as a data gradient that also reduces the BatchNorm-backward statistics of the
     layer it back-propagates into: returns (du, partials [rows,2,Cout]).  bn_aff = (scale, shift, mean,
     invstd) of that layer's forward pass, bn_y its raw output (shaped like du)."""
-    _chk(x, wp, bn_y, *bn_aff)
+    _chk(x, wp, *bn_aff)
+    _chk_st(bn_y)
     N, H, W, Cin = x.shape
     Cout = wp.shape[0]
-    y = torch.empty(N, H // 2, W // 2, Cout, dtype=torch.float32, device=x.device)
+    y = torch.empty(N, H // 2, W // 2, Cout, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     assert bn_y.shape == y.shape
     nparts = lib.dvae_conv_stat_parts_written(N * (H // 2) * (W // 2), 1)
     stats = torch.empty(nparts, 2, Cout, dtype=torch.float32, device=x.device)
     sc, sh, mean, invstd = bn_aff
     check(lib.dvae_conv4s2_dgrad_bnstat_f32(_p(x), _p(wp), _p(y), _p(stats), N, H, W, Cin, Cout, _p(bn_y), _p(sc),
-                                            _p(sh), _p(mean), _p(invstd), _stream()), 'conv4s2_dgrad_bnstat')
+                                            _p(sh), _p(mean), _p(invstd), _st(ST_Y, y) | _st(ST_BNY, bn_y), _stream()),
+          'conv4s2_dgrad_bnstat')
     return y, stats
 
 
@@ -688,19 +715,21 @@ def conv4s2_dgrad_bnstat_bnin(du_in: Tensor, in_y: Tensor, in_aff, coef_a: Tenso
     """conv4s2_dgrad_bnstat on an input that still needs its own BatchNorm backward: du_in is the gradient
     of the activation of the layer whose raw output is in_y; returns (du, partials, dx) where dx is the
     finished dL/d(in_y) (for the weight-gradient call)."""
-    _chk(du_in, in_y, wp, bn_y, coef_a, coef_b, *in_aff, *bn_aff)
+    _chk(wp, bn_y, coef_a, coef_b, *in_aff, *bn_aff)
+    _chk_st(du_in, in_y)
     assert du_in.shape == in_y.shape
     N, H, W, Cin = du_in.shape
     Cout = wp.shape[0]
     y = torch.empty(N, H // 2, W // 2, Cout, dtype=torch.float32, device=du_in.device)
     assert bn_y.shape == y.shape
-    dx = torch.empty_like(du_in)
+    dx = torch.empty_like(du_in)                # (bfloat16 when du_in is)
     nparts = lib.dvae_conv_stat_parts_written(N * (H // 2) * (W // 2), 1)
     stats = torch.empty(nparts, 2, Cout, dtype=torch.float32, device=du_in.device)
     sc, sh, mean, invstd = bn_aff
     check(lib.dvae_conv4s2_dgrad_bnstat_bnin_f32(_p(du_in), _p(in_y), _p(in_aff[0]), _p(in_aff[1]), _p(coef_a),
                                                  _p(coef_b), _p(dx), _p(wp), _p(y), _p(stats), N, H, W, Cin, Cout,
-                                                 _p(bn_y), _p(sc), _p(sh), _p(mean), _p(invstd), _stream()),
+                                                 _p(bn_y), _p(sc), _p(sh), _p(mean), _p(invstd),
+                                                 _st(ST_X, du_in) | _st(ST_INY, in_y) | _st(ST_DX, dx), _stream()),
           'conv4s2_dgrad_bnstat_bnin')
     return y, stats, dx
 
@@ -722,25 +751,28 @@ def deconv4s2_dgrad_bnstat(x: Tensor, wp: Tensor, bn_y: Tensor, bn_aff):
 
 def conv4s2_wgrad(P: Tensor, p_scale, p_shift, p_act: int, Q: Tensor, q_scale, q_shift, q_act: int) -> Tensor:
     """P [N,Hs,Ws,C1], Q [N,2Hs,2Ws,C2] -> dw [C1][C2][4][4]."""
-    _chk(P, p_scale, p_shift, Q, q_scale, q_shift)
+    _chk(p_scale, p_shift, q_scale, q_shift)
+    _chk_st(P, Q)
     N, Hs, Ws, C1 = P.shape
     C2 = Q.shape[3]
     assert Q.shape[1] == 2 * Hs and Q.shape[2] == 2 * Ws and Q.shape[0] == N
     dw = torch.empty(C1, C2, 4, 4, dtype=torch.float32, device=P.device)
     ws = workspace(lib.dvae_conv_wgrad_ws_floats(N, Hs, Ws, C1, C2), P.device)
     check(lib.dvae_conv4s2_wgrad_f32(_p(P), _p(p_scale), _p(p_shift), p_act, _p(Q), _p(q_scale), _p(q_shift),
-                                     q_act, _p(dw), _p(ws), N, Hs, Ws, C1, C2, _stream()), 'conv4s2_wgrad')
+                                     q_act, _p(dw), _p(ws), N, Hs, Ws, C1, C2, _st(ST_X, P) | _st(ST_Y, Q), _stream()),
+          'conv4s2_wgrad')
     return dw
 
 
 def deconv4s2_final_fwd(x: Tensor, scale, shift, act: int, w: Tensor, bias: Optional[Tensor],
                         out_act: int) -> Tensor:
     """x [N,H,W,Cin], w [Cin][1][4][4] -> y [N,2H,2W]."""
-    _chk(x, scale, shift, w, bias)
+    _chk(scale, shift, w, bias)
+    _chk_st(x)
     N, H, W, Cin = x.shape
     y = torch.empty(N, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
     check(lib.dvae_deconv4s2_final_fwd_f32(_p(x), _p(scale), _p(shift), act, _p(w), _p(bias), out_act, _p(y), N, H,
-                                           W, Cin, _stream()), 'deconv4s2_final_fwd')
+                                           W, Cin, _st(ST_X, x), _stream()), 'deconv4s2_final_fwd')
     return y
 
 

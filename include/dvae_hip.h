@@ -302,7 +302,28 @@ int dvae_conv4s2_fwd_ws_f32(const float* x, const float* in_scale, const float* 
                             int64_t Cin, int64_t Cout, float* ws, int64_t ws_floats, dvae_stream_t stream);
 int dvae_deconv4s2_fwd_ws_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
                               const float* wp, float* y, float* stat_partials, int64_t N, int64_t H, int64_t W,
-                              int64_t Cin, int64_t Cout, float* ws, int64_t ws_floats, dvae_stream_t stream);
+                              int64_t Cin, int64_t Cout, float* ws, int64_t ws_floats, int storage,
+                              dvae_stream_t stream);
+/* `storage` (here and in the calls below that take it; 0 = every tensor holds floats): in the bf16-MFMA mode the
+ * large few-channel activations and their gradients may be kept in HBM as bfloat16, which halves the bytes of the
+ * HBM-bound kernels around them.  A set bit says that the tensor it names holds bfloat16 elements (same shape and
+ * element order; its pointer keeps the float type of the signature): DVAE_ST_X the input x (weight gradients: P),
+ * DVAE_ST_Y the output y (weight gradients: Q), DVAE_ST_BNY bn_y (p_y), DVAE_ST_INY in_y, DVAE_ST_DX dx_out.
+ * Only in bf16 mode, and only the combinations that a training step of the decoder's last block (64 -> 32 channels
+ * on 16 x 16, then 32 -> 1) produces have kernels, -EINVAL otherwise:
+ *   dvae_deconv4s2_fwd_ws_f32           64 -> 32 row kernel, no fused statistics of a layer below:  DVAE_ST_Y
+ *   dvae_deconv4s2_final_fwd_f32        Cin = 32:                                                   DVAE_ST_X
+ *   dvae_conv4s2_wgrad_f32              single-channel Q, C1 = 32:                                  DVAE_ST_X
+ *                                       64 x 32 row kernel with a transformed P:                    DVAE_ST_Y
+ *   dvae_conv4s2_dgrad_bnstat_f32       Cin = 1, Cout = 32:                               DVAE_ST_Y | DVAE_ST_BNY
+ *   dvae_conv4s2_dgrad_bnstat_bnin_f32  32 -> 64 row kernel:                   DVAE_ST_X | DVAE_ST_INY | DVAE_ST_DX
+ * What a kernel writes as bfloat16 is the round-to-nearest-even of the fp32 value it would have written; statistics
+ * are always reduced from the fp32 accumulators, before rounding.  No counterpart in the reference. */
+#define DVAE_ST_X 1
+#define DVAE_ST_Y 2
+#define DVAE_ST_BNY 4
+#define DVAE_ST_INY 8
+#define DVAE_ST_DX 16
 /* The two kernels above used as data gradients inside a conv -> BatchNorm -> LeakyReLU stack (autograd of
  * models/encoders.py:32-36 and models/decoders.py:40-45): x is dL/d(raw output of the next layer), y
  * receives du = dL/d(activation of this layer), unchanged; in the same pass the kernel also reduces what
@@ -313,7 +334,7 @@ int dvae_deconv4s2_fwd_ws_f32(const float* x, const float* in_scale, const float
 int dvae_conv4s2_dgrad_bnstat_f32(const float* x, const float* wp, float* y, float* stat_partials, int64_t N,
                                   int64_t H, int64_t W, int64_t Cin, int64_t Cout, const float* bn_y,
                                   const float* bn_scale, const float* bn_shift, const float* bn_mean,
-                                  const float* bn_invstd, dvae_stream_t stream);
+                                  const float* bn_invstd, int storage, dvae_stream_t stream);
 /* dvae_conv4s2_dgrad_bnstat_f32 whose input has not been through its own BatchNorm backward yet (the
  * decoder's conv-transpose -> BatchNorm -> LeakyReLU blocks, models/decoders.py:40-45, walked backwards):
  * du_in is dL/d(activation) of the layer above, in_y that layer's raw output, in_scale/in_shift its
@@ -328,7 +349,8 @@ int dvae_conv4s2_dgrad_bnstat_bnin_f32(const float* du_in, const float* in_y, co
                                        float* dx_out, const float* wp, float* y, float* stat_partials,
                                        int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                                        const float* bn_y, const float* bn_scale, const float* bn_shift,
-                                       const float* bn_mean, const float* bn_invstd, dvae_stream_t stream);
+                                       const float* bn_mean, const float* bn_invstd, int storage,
+                                       dvae_stream_t stream);
 /* The transposed-conv counterpart (the encoder's conv -> BatchNorm -> LeakyReLU blocks,
  * models/encoders.py:32-36, walked backwards); same arguments and rules. */
 int dvae_deconv4s2_bnin_supported(int64_t H, int64_t W, int64_t Cin, int64_t Cout);
@@ -352,7 +374,7 @@ int64_t dvae_conv_wgrad_ws_floats(int64_t N, int64_t Hs, int64_t Ws, int64_t C1,
 int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, const float* p_shift, int p_act,
                            const float* Q, const float* q_scale, const float* q_shift, int q_act,
                            float* dw, float* ws, int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2,
-                           dvae_stream_t stream);
+                           int storage, dvae_stream_t stream);
 /* Weight gradient of the first encoder convolution (single-channel Q = the frames, models/encoders.py:32)
  * whose P = dL/d(activation) has not been through that layer's BatchNorm backward: du, the layer's raw
  * output p_y, its forward affine and the vectors of dvae_bn_bwd_coeffs_f32; P becomes scale*dz + A*y + B
@@ -375,7 +397,7 @@ int dvae_conv4s2_wgrad_bnq_f32(const float* P, const float* p_scale, const float
  * x [N,H,W,Cin] (+ load-time transform), w torch layout [Cin][1][4][4], y [N,2H,2W]. Cin%4==0. */
 int dvae_deconv4s2_final_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
                                  const float* w, const float* bias, int out_act, float* y, int64_t N,
-                                 int64_t H, int64_t W, int64_t Cin, dvae_stream_t stream);
+                                 int64_t H, int64_t W, int64_t Cin, int storage, dvae_stream_t stream);
 
 /* ---- LSTM (nn.LSTM at models/encoders.py:145-152, models/decoders.py:94-100,221-226), gate order
  *      i,f,g,o.  One call advances one layer/direction set by one time step for all B rows:

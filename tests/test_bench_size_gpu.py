@@ -148,9 +148,9 @@ def test_gemm_at_bench_size(ops, M, N, K):
     assert rel_err(out, base.double() + d.double().t() @ a.double()) < 5e-6
 
 
-# bf16-MFMA variant, full width, batch 256: bar on the per-tensor gradient error = 1.5 x the worst value measured on
-# MI355X (profiles/r3_parity_b256.txt)
-BF16_GRAD_BAR = 2e-1
+# bf16-MFMA variant (with the decoder's largest tensors stored as bf16), full width, batch 256: bar on the per-tensor
+# gradient error = 1.5 x the worst value measured on MI355X (1.063e-1, profiles/r3_parity_b256.txt)
+BF16_GRAD_BAR = 1.6e-1
 
 
 def _record(title, header, rows):

@@ -1,0 +1,140 @@
+"""bf16 storage of the decoder's largest tensors (bf16-MFMA mode): every kernel that reads or writes a tensor as
+bfloat16 against the same kernel on fp32 storage holding the same (bf16-representable) values.
+
+What a kernel READS as bf16 it converts to the bf16 MFMA operand it would have made of the fp32 value anyway, so
+results on bf16-representable inputs are required to be EQUAL; what it WRITES as bf16 is the round-to-nearest-even
+of the fp32 value it would have written (checked with torch's own conversion), and the BatchNorm statistics it
+reduces beside the store come from the fp32 accumulators, so they are required to be equal too.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ops():
+    from hipvae import ops as _ops
+    assert torch.cuda.is_available()
+    _ops.set_precision('bf16')
+    yield _ops
+    _ops.set_precision('fp32')
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def aff_of(C, seed):
+    gamma, beta = 1 + 0.3 * rnd(C, seed=seed), 0.2 * rnd(C, seed=seed + 1)
+    mean, invstd = 0.1 * rnd(C, seed=seed + 2), 1 + 0.2 * rnd(C, seed=seed + 3).abs()
+    return (gamma * invstd).contiguous(), (beta - mean * gamma * invstd).contiguous(), mean, invstd
+
+
+@pytest.mark.parametrize('N', [3, 70])
+def test_last_block_writes_and_reads_bf16(ops, N):
+    x = rnd(N, 16, 16, 64, seed=1)
+    sc, sh, _, _ = aff_of(64, 2)
+    wp = ops.pack_deconv_w(rnd(64, 32, 4, 4, seed=6, scale=0.2))
+    y32, s32, n32 = ops.deconv4s2_fwd(x, sc, sh, ops.ACT_LRELU, wp, True)
+    y16, s16, n16 = ops.deconv4s2_fwd(x, sc, sh, ops.ACT_LRELU, wp, True, out_bf16=True)
+    assert y16.dtype == torch.bfloat16 and y16.shape == y32.shape and n16 == n32
+    assert torch.equal(y16, y32.bfloat16())
+    assert torch.equal(s16, s32)
+
+
+@pytest.mark.parametrize('N,Cin', [(3, 32), (70, 32)])
+def test_final_layer_reads_bf16(ops, N, Cin):
+    H = 32
+    x = rnd(N, H, H, Cin, seed=7).bfloat16()
+    sc, sh, _, _ = aff_of(Cin, 8)
+    w, b = rnd(Cin, 1, 4, 4, seed=12, scale=0.3), rnd(1, seed=13)
+    got = ops.deconv4s2_final_fwd(x, sc, sh, ops.ACT_LRELU, w, b, ops.ACT_SIGMOID)
+    ref = ops.deconv4s2_final_fwd(x.float(), sc, sh, ops.ACT_LRELU, w, b, ops.ACT_SIGMOID)
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize('N', [3, 70])
+def test_final_layer_backward_on_bf16(ops, N):
+    """weight gradient of the one-channel layer with its input stored as bf16, and its data gradient written as bf16
+    beside the BatchNorm-backward sums of the block below"""
+    y6 = rnd(N, 32, 32, 32, seed=14).bfloat16()
+    aff = aff_of(32, 15)
+    dlogit = rnd(N, 64, 64, 1, seed=19, scale=0.1)
+    w = rnd(32, 1, 4, 4, seed=20, scale=0.3)
+    dw16 = ops.conv4s2_wgrad(y6, aff[0], aff[1], ops.ACT_LRELU, dlogit, None, None, ops.ACT_NONE)
+    dw32 = ops.conv4s2_wgrad(y6.float(), aff[0], aff[1], ops.ACT_LRELU, dlogit, None, None, ops.ACT_NONE)
+    assert torch.equal(dw16, dw32)
+    du16, p16 = ops.conv4s2_dgrad_bnstat(dlogit, w, y6, aff, out_bf16=True)
+    du32, p32 = ops.conv4s2_dgrad_bnstat(dlogit, w, y6.float(), aff)
+    assert du16.dtype == torch.bfloat16
+    assert torch.equal(du16, du32.bfloat16())
+    assert torch.equal(p16, p32)
+
+
+@pytest.mark.parametrize('N', [3, 70])
+def test_last_block_backward_on_bf16(ops, N):
+    """the data-gradient kernel that takes du through the block's BatchNorm backward, on bf16 du and y, handing a
+    bf16 dL/dy to the weight-gradient kernel"""
+    du = rnd(N, 32, 32, 32, seed=21).bfloat16()
+    y6 = rnd(N, 32, 32, 32, seed=22).bfloat16()
+    aff = aff_of(32, 23)
+    ca, cb = 0.01 * rnd(32, seed=27), 0.01 * rnd(32, seed=28)
+    wp = ops.pack_conv_w(rnd(64, 32, 4, 4, seed=29, scale=0.2))
+    y3 = rnd(N, 16, 16, 64, seed=30)
+    aff3 = aff_of(64, 31)
+    assert ops.conv4s2_bnin_supported(du, 64)
+    g_du, g_parts, g_dx = ops.conv4s2_dgrad_bnstat_bnin(du, y6, aff, ca, cb, wp, y3, aff3)
+    r_du, r_parts, r_dx = ops.conv4s2_dgrad_bnstat_bnin(du.float(), y6.float(), aff, ca, cb, wp, y3, aff3)
+    assert g_dx.dtype == torch.bfloat16 and g_du.dtype == torch.float32
+    assert torch.equal(g_dx, r_dx.bfloat16())
+    assert torch.equal(g_du, r_du) and torch.equal(g_parts, r_parts)
+    dw16 = ops.conv4s2_wgrad(y3, aff3[0], aff3[1], ops.ACT_LRELU, g_dx, None, None, ops.ACT_NONE)
+    dw32 = ops.conv4s2_wgrad(y3, aff3[0], aff3[1], ops.ACT_LRELU, g_dx.float(), None, None, ops.ACT_NONE)
+    assert torch.equal(dw16, dw32)
+
+
+def test_bf16_tensors_are_refused_where_no_kernel_takes_them(ops):
+    x = rnd(3, 4, 4, 256, seed=40).bfloat16()
+    wp = ops.pack_deconv_w(rnd(256, 128, 4, 4, seed=41, scale=0.1))
+    with pytest.raises(RuntimeError):
+        ops.deconv4s2_fwd(x, None, None, ops.ACT_NONE, wp, False)
+    # the 64 -> 32 row kernel writes bf16 but has no variant that also reads it, nor does the 64-channel final layer
+    x = rnd(3, 16, 16, 64, seed=44).bfloat16()
+    wp = ops.pack_deconv_w(rnd(64, 32, 4, 4, seed=45, scale=0.1))
+    with pytest.raises(RuntimeError):
+        ops.deconv4s2_fwd(x, None, None, ops.ACT_NONE, wp, False, out_bf16=True)
+    with pytest.raises(RuntimeError):
+        ops.deconv4s2_final_fwd(x, None, None, ops.ACT_NONE, rnd(64, 1, 4, 4, seed=46), rnd(1, seed=47), ops.ACT_SIGMOID)
+    ops.set_precision('fp32')
+    x = rnd(3, 16, 16, 64, seed=42)
+    wp = ops.pack_deconv_w(rnd(64, 32, 4, 4, seed=43, scale=0.1))
+    with pytest.raises(RuntimeError):
+        ops.deconv4s2_fwd(x, None, None, ops.ACT_NONE, wp, False, out_bf16=True)
+
+
+def test_step_on_bf16_storage_follows_the_fp32_storage_step(ops, monkeypatch):
+    """DisentangledVAE training step in bf16 mode with and without bf16 storage: same loss to 1e-3 relative, every
+    gradient within 3e-2 relative L2 of the other (the bf16-mode step itself is held to the oracle elsewhere)."""
+    import models
+    from hipvae import losses
+
+    def run(storage):
+        monkeypatch.setattr(ops, 'USE_BF16_STORAGE', storage)
+        torch.manual_seed(5)
+        model = models.DisentangledVAE().cuda().train()
+        v = torch.rand(4, 20, 1, 64, 64, generator=torch.Generator().manual_seed(9)).cuda()
+        torch.manual_seed(11)                           # (the reparameterisation draws)
+        out = model(v)
+        loss = losses.disentangled_loss(out, v, beta=2.0, beta_content=2.0, beta_motion=1.0)['total_loss']
+        loss.backward()
+        return float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert abs(l1 - l0) <= 1e-3 * abs(l0)
+    assert g0.keys() == g1.keys()
+    assert any(not torch.equal(g0[n], g1[n]) for n in g0)        # (the second run did take the bf16 route)
+    worst = max(float((g1[n] - g0[n]).norm() / g0[n].norm().clamp_min(1e-30)) for n in g0)
+    assert worst < 3e-2, worst
