@@ -470,21 +470,65 @@ def main():
         if not use_dp:
             gstep = cls(model, opt, loss_of, ring[0], gradient_clip=t['gradient_clip'])
             return lambda i: gstep(ring[i % len(ring)])
-        # Several ranks: should capture fail on any rank (the collectives' own threads share the device with
-        # the capturing thread), every rank takes the eager data-parallel step instead - the same kernels,
-        # launched one by one, with the bucketed all-reduces overlapped with backward - and the result line says so.
-        gstep, why = None, ''
+        # Several ranks.  Ranks may only change path together, and only at a point where all of them stand between
+        # the same two collectives:
+        #  1. pre-flight: one eager forward + backward per rank, no collective anywhere in it.  A rank that cannot
+        #     run the model at all (out of memory, a kernel refusing a shape) shows here; the flag is reduced with
+        #     MIN and every rank stops with the same message.
+        #  2. the constructor's warm-up steps issue collectives; a rank that fails BETWEEN two of them leaves its
+        #     peers inside one, and no flag can be exchanged any more: that rank re-raises, the job ends (the
+        #     launcher takes the peers down), nothing falls back.
+        #  3. capture issues no collective.  Should it fail on any rank (the collectives' own threads share the device
+        #     with the capturing thread), every rank has finished the same warm-up collectives, the flag exchange
+        #     below is the next collective on all of them, and all take the eager data-parallel step instead - the
+        #     same kernels launched one by one, bucketed all-reduces overlapped with backward; the result line says so.
+        # DVAE_BENCH_FAIL_CAPTURE rehearses these: '1' (before the constructor), 'capture[:rank]', 'warmup[:rank]'.
+        knob, _, knob_rank = os.environ.get('DVAE_BENCH_FAIL_CAPTURE', '').partition(':')
+        knob_here = knob != '' and (knob_rank == '' or int(knob_rank) == rank)
+
+        def agreed(flag_ok):
+            ok = torch.tensor([1 if flag_ok else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            return int(ok.item()) == 1
+
+        why = ''
         try:
-            if os.environ.get('DVAE_BENCH_FAIL_CAPTURE') == '1':         # rehearsal of the fallback below
-                raise RuntimeError('DVAE_BENCH_FAIL_CAPTURE=1')
-            gstep = cls(model, opt, loss_of, ring[0], gradient_clip=t['gradient_clip'])
+            opt.zero_grad(set_to_none=True)
+            loss_of(model, ring[0])['total_loss'].backward()
+            opt.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
         except Exception as e:                                          # noqa: BLE001
             why = f'{type(e).__name__}: {e}'
+        if not agreed(why == ''):
+            raise RuntimeError(f'rank {rank}: the training step does not run on every rank ({why or "failed on another rank"})')
+
+        class Rehearsed(cls):
+            def _capture(self):
+                if knob == 'capture' and knob_here:
+                    raise RuntimeError('DVAE_BENCH_FAIL_CAPTURE=capture')
+                super()._capture()
+
+            def _step(self):
+                losses = super()._step()
+                if knob == 'warmup' and knob_here:
+                    raise RuntimeError('DVAE_BENCH_FAIL_CAPTURE=warmup')
+                return losses
+
+        gstep = None
+        try:
+            if knob == '1' and knob_here:
+                raise RuntimeError('DVAE_BENCH_FAIL_CAPTURE=1')
+            gstep = (Rehearsed if knob in ('capture', 'warmup') else cls)(model, opt, loss_of, ring[0],
+                                                                         gradient_clip=t['gradient_clip'])
+        except Exception as e:                                          # noqa: BLE001
+            why = f'{type(e).__name__}: {e}'
+            if not (knob == '1' and knob_here) and getattr(e, 'dvae_phase', 'warmup') != 'capture':
+                print(f'[bench] rank {rank}: the data-parallel step failed between its warm-up collectives ({why}); '
+                      f'the other ranks cannot be told: stopping', file=sys.stderr, flush=True)
+                raise
             print(f'[bench] rank {rank}: captured data-parallel step failed ({why}); eager step instead',
                   file=sys.stderr, flush=True)
-        ok = torch.tensor([0 if gstep is None else 1], device=dev, dtype=torch.int32)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 1:
+        if agreed(gstep is not None):
             return lambda i: gstep(ring[i % len(ring)])
         del gstep
         torch.cuda.synchronize()

@@ -323,20 +323,68 @@ class SigmoidTail:
     carries it onto the [B, T, ...] view); a loss node that finds it writes the logit-form gradient, notes the
     tensor here and returns it as its gradient; DecoderCNN.backward recognises its own record's tensor by address.
     Any other gradient that autograd adds on the way (the reconstruction used twice) arrives as a different
-    tensor and is corrected for, so the result is the same whichever path runs."""
-    __slots__ = ('dlogit', 'dbias')
+    tensor and is corrected for, so the result is the same whichever path runs.
+
+    What travels through autograd as "the gradient of recon" on this path is the logit form, so the path is only
+    taken when nobody can see or change that tensor (`tail_usable`): the reconstruction has no tensor hooks and does
+    not retain its gradient, and the decoder's node is part of the backward pass that is running (it is not when
+    the caller asks for `torch.autograd.grad(loss, recon)`).  A record is stamped with the backward pass that wrote
+    it; DecoderCNN.backward drops one left by a pass that never reached it (an exception on the way).  Not covered:
+    `torch.autograd.grad(loss, [recon, *parameters])`, which runs the decoder's node AND captures recon's gradient
+    -- DVAE_FUSE_TAIL=0 for such callers."""
+    __slots__ = ('dlogit', 'dbias', 'node', 'task')
 
     def __init__(self):
         self.dlogit: Optional[Tensor] = None
         self.dbias: Optional[Tensor] = None
+        self.node = None          # DecoderCNN's autograd node (bind_tail)
+        self.task = -1            # the backward pass (autograd graph task) that wrote dlogit
 
 
 FUSE_TAIL = os.environ.get('DVAE_FUSE_TAIL', '1') != '0'
 
 
+def _backward_pass_id() -> int:
+    f = getattr(torch._C, '_current_graph_task_id', None)
+    return int(f()) if f is not None else -1
+
+
+def _observed(t: Tensor) -> bool:
+    """whether somebody will see (retain_grad) or may rewrite (a tensor hook) the gradient that reaches t"""
+    return bool(t.retains_grad) or bool(getattr(t, '_backward_hooks', None))
+
+
+def bind_tail(frames: Tensor) -> Tensor:
+    """notes DecoderCNN's autograd node in the hand-off record of the tensor it returned"""
+    tail = getattr(frames, '_dvae_tail', None)
+    if tail is not None:
+        tail.node = frames.grad_fn
+    return frames
+
+
 def sigmoid_tail(recon: Tensor) -> Optional[SigmoidTail]:
-    """The hand-off record of a reconstruction that came straight from DecoderCNN (None otherwise)."""
-    return getattr(recon, '_dvae_tail', None) if FUSE_TAIL else None
+    """The hand-off record of a reconstruction that came straight from DecoderCNN (None otherwise, or when its
+    gradient is observed).  Called by the loss functions' forward: whatever an earlier backward pass left in the
+    record is dropped here."""
+    tail = getattr(recon, '_dvae_tail', None) if FUSE_TAIL else None
+    if tail is None:
+        return None
+    tail.dlogit = tail.dbias = None
+    return None if _observed(recon) else tail
+
+
+def tail_usable(tail: Optional[SigmoidTail], recon: Tensor) -> bool:
+    """At the loss node's backward: may the logit-form gradient be handed over in this backward pass?"""
+    if tail is None or tail.dlogit is not None or _observed(recon):
+        return False
+    will_run = getattr(torch._C, '_will_engine_execute_node', None)
+    if tail.node is not None and will_run is not None:
+        try:
+            if not will_run(tail.node):
+                return False
+        except RuntimeError:          # not inside a backward pass that knows its nodes
+            return False
+    return True
 
 
 def as_clips(frames: Tensor, B: int, T: int) -> Tensor:
@@ -425,6 +473,8 @@ class DecoderCNN(torch.autograd.Function):
         if tail.dlogit is not None:
             fused, fused_b = tail.dlogit, tail.dbias
             tail.dlogit = tail.dbias = None
+            if tail.task != _backward_pass_id():
+                fused = None                       # left by a backward pass that never got here
         if fused is not None and drecon.data_ptr() == fused.data_ptr() and drecon.numel() == fused.numel():
             dlogit, d_final_b = fused.view_as(recon), fused_b          # the loss node wrote d/d(logit) already
         elif fused is not None:
@@ -715,7 +765,6 @@ class LSTMEncoder(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.permute3(dout, (T, B, I0), (1, 0, 2))
-        ctx.layers = None
         return (dx, None, None, *grads)
 
 

@@ -57,32 +57,43 @@ class GraphedTrainStep:
         side = capture_stream(example_video.device)
         side.wait_stream(torch.cuda.current_stream())
         rehearsed = None
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                with (rng.draw_slots() if inject else contextlib.nullcontext()) as rehearsed:
-                    self._step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self._capture_stream = side          # capture goes on the stream the warm-up ran on (see capture_stream)
-        # the draw buffers exist before capture begins (see rng.draw_slots), one per draw of the rehearsed step
-        self.eps_slots = [torch.zeros_like(b) for b in rehearsed] if inject else None
-        with (rng.draw_slots(self.eps_slots) if inject else contextlib.nullcontext()):
-            self._capture()
-        # undo the warm-up steps
-        with torch.no_grad():
-            for t, s in zip(tensors, snap):
-                t.copy_(s)
-            for p, st in optimizer.state.items():
-                old = opt_snap.get(p, {})
-                for k in ('exp_avg', 'exp_avg_sq', 'step'):
-                    if k in st:
-                        if k in old:
-                            st[k].copy_(old[k])
-                        else:
-                            st[k].zero_()
-            optimizer._replayed = 0
-            dyn.copy_(dyn_snap)
-        torch.cuda.synchronize()
+        # 'warmup' -> 'capture' -> 'ready': where an exception of this constructor came from (a data-parallel caller
+        # may only fall back to another path by agreement when every rank got through the warm-up collectives)
+        self.phase = 'warmup'
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    with (rng.draw_slots() if inject else contextlib.nullcontext()) as rehearsed:
+                        self._step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.phase = 'capture'
+            self._capture_stream = side      # capture goes on the stream the warm-up ran on (see capture_stream)
+            # the draw buffers exist before capture begins (see rng.draw_slots), one per draw of the rehearsed step
+            self.eps_slots = [torch.zeros_like(b) for b in rehearsed] if inject else None
+            with (rng.draw_slots(self.eps_slots) if inject else contextlib.nullcontext()):
+                self._capture()
+            self.phase = 'ready'
+        except BaseException as e:
+            e.dvae_phase = self.phase
+            raise
+        finally:
+            # undo the warm-up steps, also when capture failed: whoever takes another path starts from the same state
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for t, s in zip(tensors, snap):
+                    t.copy_(s)
+                for p, st in optimizer.state.items():
+                    old = opt_snap.get(p, {})
+                    for k in ('exp_avg', 'exp_avg_sq', 'step'):
+                        if k in st:
+                            if k in old:
+                                st[k].copy_(old[k])
+                            else:
+                                st[k].zero_()
+                optimizer._replayed = 0
+                dyn.copy_(dyn_snap)
+            torch.cuda.synchronize()
 
     def _capture(self):
         # thread-local capture mode: other threads of the process (a DataLoader's pinning thread, a checkpoint

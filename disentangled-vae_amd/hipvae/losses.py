@@ -10,7 +10,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
-from .functional import sigmoid_tail
+from .functional import _backward_pass_id, sigmoid_tail, tail_usable
 
 Tensor = torch.Tensor
 _KIND = {'mse': 0, 'bce': 1}
@@ -19,9 +19,9 @@ _KIND = {'mse': 0, 'bce': 1}
 def _recon_grad(tail, recon, target, gs, kind, tw):
     """Gradient of the reconstruction terms: in logit form, handed to the decoder that produced `recon`, when that
     decoder left a hand-off record and nobody has used it yet in this backward pass (see functional.SigmoidTail)."""
-    if tail is not None and tail.dlogit is None:
+    if tail_usable(tail, recon):
         d, db = ops.recon_loss_bwd_logit(recon, target, gs, kind, tw)
-        tail.dlogit, tail.dbias = d, db
+        tail.dlogit, tail.dbias, tail.task = d, db, _backward_pass_id()
         return d
     return ops.recon_loss_bwd(recon, target, gs, kind, tw)
 

@@ -41,8 +41,8 @@ class CNNDecoder(nn.Module):
         """`replicas` (not in the reference): x stands for that many identical copies of each of its rows, see
         hipvae.functional.DecoderCNN."""
         ws, gs, bs, handles = _stack_tensors(self.deconv)
-        return HF.DecoderCNN.apply(x, self.training, handles, int(replicas), self.fc[0].weight, self.fc[0].bias,
-                                   self.final.weight, self.final.bias, *ws, *gs, *bs)
+        return HF.bind_tail(HF.DecoderCNN.apply(x, self.training, handles, int(replicas), self.fc[0].weight,
+                                                self.fc[0].bias, self.final.weight, self.final.bias, *ws, *gs, *bs))
 
 
 def _lstm_layer_weights(lstm: nn.LSTM):

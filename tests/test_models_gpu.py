@@ -177,6 +177,98 @@ def test_a_second_consumer_of_the_reconstruction_is_added_correctly_to_the_logit
         assert rel(one[n].cpu().numpy(), two[n].cpu().numpy()) < 2e-5, (n, rel(one[n].cpu().numpy(), two[n].cpu().numpy()))
 
 
+def _step_for_tail(kind='disentangled'):
+    from hipvae import rng
+    g = load_step(kind)
+    m = build(kind, g).train()
+    video = torch.from_numpy(g['video']).cuda()
+    eps = [torch.from_numpy(g[f'eps{k}']) for k in range(2) if f'eps{k}' in g]
+    with rng.inject_eps(eps):
+        out = m(video)
+    return m, video, out
+
+
+def _total(kind, out, video):
+    return loss_of(kind, out, video, SETTINGS['tcfg'][kind], SETTINGS['beta'])['total_loss']
+
+
+def test_whoever_observes_the_gradient_of_the_reconstruction_sees_the_true_one():
+    """the logit-form hand-off is only taken when nobody can see or rewrite the tensor that travels as "the gradient
+    of recon": autograd.grad(total, recon), retain_grad() and a tensor hook all get d(total)/d(recon), and the
+    parameter gradients stay those of the two-pass path"""
+    from hipvae import functional as HF
+    kind = 'disentangled'
+    want = _grads_of_step(kind, fuse=False)
+    old, HF.FUSE_TAIL = HF.FUSE_TAIL, False
+    try:
+        m, video, out = _step_for_tail(kind)
+        recon = as_dict(kind, out)['recon']
+        (true_grad,) = torch.autograd.grad(_total(kind, out, video), recon)
+    finally:
+        HF.FUSE_TAIL = old
+    assert HF.FUSE_TAIL
+    # asked for directly: the decoder's node does not run in that backward pass
+    m, video, out = _step_for_tail(kind)
+    recon = as_dict(kind, out)['recon']
+    total = _total(kind, out, video)
+    (got,) = torch.autograd.grad(total, recon, retain_graph=True)
+    assert torch.equal(got, true_grad)
+    # ... and a full backward pass over the same graph afterwards is still right
+    total.backward()
+    for n, p in m.named_parameters():
+        assert rel(p.grad.cpu().numpy(), want[n].cpu().numpy()) < 1e-5, n
+    # retained
+    m, video, out = _step_for_tail(kind)
+    recon = as_dict(kind, out)['recon']
+    recon.retain_grad()
+    _total(kind, out, video).backward()
+    assert torch.equal(recon.grad, true_grad)
+    for n, p in m.named_parameters():
+        assert rel(p.grad.cpu().numpy(), want[n].cpu().numpy()) < 1e-5, n
+    # a hook that rewrites it, registered after the loss was formed: the decoder must see the rewritten TRUE gradient
+    m, video, out = _step_for_tail(kind)
+    recon = as_dict(kind, out)['recon']
+    total = _total(kind, out, video)
+    seen = []
+    recon.register_hook(lambda g: (seen.append(g.clone()), 0.5 * g)[1])
+    total.backward()
+    assert torch.equal(seen[0], true_grad)
+    half = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m2, video, out = _step_for_tail(kind)
+    old, HF.FUSE_TAIL = HF.FUSE_TAIL, False
+    try:
+        recon = as_dict(kind, out)['recon']
+        total = _total(kind, out, video)
+        recon.register_hook(lambda g: 0.5 * g)
+        total.backward()
+    finally:
+        HF.FUSE_TAIL = old
+    for n, p in m2.named_parameters():
+        assert rel(half[n].cpu().numpy(), p.grad.cpu().numpy()) < 1e-5, n
+
+
+def test_two_backward_passes_over_one_graph_and_a_record_left_behind():
+    from hipvae import functional as HF
+    kind = 'disentangled'
+    want = _grads_of_step(kind, fuse=True)
+    m, video, out = _step_for_tail(kind)
+    total = _total(kind, out, video)
+    total.backward(retain_graph=True)
+    first = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    total.backward()
+    for n, p in m.named_parameters():
+        assert torch.equal(first[n], want[n]) and torch.equal(p.grad, want[n]), n
+    # a backward pass that wrote the record and never reached the decoder (here: faked) must not leak into the next
+    m, video, out = _step_for_tail(kind)
+    tail = as_dict(kind, out)['recon']._dvae_tail
+    total = _total(kind, out, video)
+    tail.dlogit, tail.dbias, tail.task = torch.full_like(as_dict(kind, out)['recon'], 7.0), torch.ones(1, device='cuda'), -12345
+    total.backward()
+    for n, p in m.named_parameters():
+        assert rel(p.grad.cpu().numpy(), want[n].cpu().numpy()) < 1e-5, n
+
+
 def test_second_stream_changes_no_bit_of_the_gradients():
     from hipvae import functional as HF
     two = _grads_of_step('disentangled')
