@@ -1374,6 +1374,15 @@ static bool launch_deconv_rows_st(const ConvArgs& g, dim3 grid, hipStream_t stre
       return true;
     }
   }
+  if constexpr (CI == 32 && CO == 16 && BNS && BNIN) {
+    // data gradient of the motion encoder's second convolution: reads the first layer's raw output (bf16) for the
+    // BatchNorm-backward sums and writes the gradient of its activation as bf16
+    if (g.st == (DVAE_ST_Y | DVAE_ST_BNY)) {
+      DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, XF, BNS, BNIN, true, DVAE_ST_Y | DVAE_ST_BNY>), grid, dim3(256), 0,
+                  stream, g);
+      return true;
+    }
+  }
   return false;
 }
 template <int CI, int CO, int WPE, bool XF, bool BNS, bool BNIN>
@@ -1383,6 +1392,13 @@ static bool launch_conv_rows_st(const ConvArgs& g, dim3 grid, size_t lds, hipStr
     if (g.st == (DVAE_ST_X | DVAE_ST_INY | DVAE_ST_DX)) {
       DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, XF, BNS, BNIN, true, DVAE_ST_X | DVAE_ST_INY | DVAE_ST_DX>), grid,
                   dim3(CO * 4), lds, stream, g);
+      return true;
+    }
+  }
+  if constexpr (CI == 16 && CO == 32 && XF && !BNS && !BNIN) {
+    // the motion encoder's second convolution reads the first layer's raw output as bf16
+    if (g.st == DVAE_ST_X) {
+      DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, XF, BNS, BNIN, true, DVAE_ST_X>), grid, dim3(CO * 4), lds, stream, g);
       return true;
     }
   }
@@ -1555,8 +1571,11 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   if (g.st != 0) {                                                                              \
     if (NCB == 2 && bns && g.st == (DVAE_ST_Y | DVAE_ST_BNY))                                   \
       DVAE_LAUNCH((conv_c1_kernel<2, true, DVAE_ST_Y | DVAE_ST_BNY>), grid, dim3(256), 0, stream, g); \
+    else if (NCB == 1 && !bns && g.st == DVAE_ST_Y)                                             \
+      DVAE_LAUNCH((conv_c1_kernel<1, false, DVAE_ST_Y>), grid, dim3(256), 0, stream, g);        \
     else {                                                                                      \
-      dvae_set_error("%s: the single-channel-input kernel takes bf16 storage for y and bn_y together, 32 channels", name); \
+      dvae_set_error("%s: the single-channel-input kernel takes bf16 storage for y and bn_y together (32 channels) " \
+                     "or for a plain output of up to 16 channels", name);                       \
       return -EINVAL;                                                                           \
     }                                                                                           \
   } else if (bns) DVAE_LAUNCH((conv_c1_kernel<NCB, true>), grid, dim3(256), 0, stream, g);       \
@@ -1735,10 +1754,10 @@ extern "C" int64_t dvae_conv_fwd_ws_floats(int transposed, int64_t N, int64_t H,
 extern "C" int dvae_conv4s2_fwd_ws_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
                                        const float* wp, float* y, float* stat_partials, int64_t N, int64_t H,
                                        int64_t W, int64_t Cin, int64_t Cout, float* ws, int64_t ws_floats,
-                                       dvae_stream_t stream) {
+                                       int storage, dvae_stream_t stream) {
   return conv4s2_fwd_impl("conv4s2_fwd", x, in_scale, in_shift, in_act, wp, y, stat_partials, N, H, W, Cin, Cout,
                           BnBwdStat{nullptr, nullptr, nullptr, nullptr, nullptr}, ST(stream),
-                          BnBwdInput{nullptr, nullptr, nullptr, nullptr}, ws, ws_floats);
+                          BnBwdInput{nullptr, nullptr, nullptr, nullptr}, ws, ws_floats, storage);
 }
 
 extern "C" int dvae_deconv4s2_fwd_ws_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
@@ -1799,13 +1818,13 @@ extern "C" int dvae_deconv4s2_dgrad_bnstat_bnin_f32(const float* du_in, const fl
                                                     float* dx_out, const float* wp, float* y, float* stat_partials,
                                                     int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                                                     const float* bn_y, const float* bn_scale, const float* bn_shift,
-                                                    const float* bn_mean, const float* bn_invstd,
+                                                    const float* bn_mean, const float* bn_invstd, int storage,
                                                     dvae_stream_t stream) {
   DVAE_REQUIRE(bn_y != nullptr && in_y != nullptr, "deconv4s2_dgrad_bnstat_bnin: bn_y / in_y is null");
   DVAE_REQUIRE(dvae_deconv4s2_bnin_supported(H, W, Cin, Cout), "deconv4s2_dgrad_bnstat_bnin: unsupported shape or precision");
   return deconv4s2_fwd_impl("deconv4s2_dgrad_bnstat_bnin", du_in, in_scale, in_shift, DVAE_ACT_NONE, wp, y, stat_partials,
                             N, H, W, Cin, Cout, BnBwdStat{bn_y, bn_scale, bn_shift, bn_mean, bn_invstd}, ST(stream),
-                            BnBwdInput{in_y, in_a, in_b, dx_out});
+                            BnBwdInput{in_y, in_a, in_b, dx_out}, nullptr, 0, storage);
 }
 
 // Host helper used by the Python side through dvae_conv_stat_parts is an upper bound; the exact
@@ -1997,8 +2016,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(WgradArgs g) {
   constexpr int ncb = NCB;
   // P stored as bf16 with 32 channels: row i of channel block cb stands for channel 2i + cb instead of 16cb + i, so
   // that one dword load brings a lane both of its channels (2-byte loads cost as much per element as dwords)
-  constexpr bool PAIR = (ST & DVAE_ST_X) != 0;
-  static_assert(!PAIR || (NCB == 2 && !BNP), "bf16 P: the 32-channel variant without a BatchNorm-backward P");
+  constexpr bool PAIR = (ST & DVAE_ST_X) != 0 && NCB == 2;
+  // ... with 16 channels two neighbouring lanes fetch the same dword and take a half each (P and p_y alike)
+  constexpr bool HALF = (ST & DVAE_ST_X) != 0 && NCB == 1;
+  static_assert(!PAIR || !BNP, "bf16 P with 32 channels: the variant without a BatchNorm-backward P");
+  static_assert(!HALF || (ST & DVAE_ST_BNY) != 0 || !BNP, "bf16 P with 16 channels: p_y is bf16 as well");
+  static_assert((ST & DVAE_ST_X) != 0 || ST == 0, "p_y is only stored as bf16 together with P");
   auto chan = [](int cb, int i) { return PAIR ? 2 * i + cb : cb * 16 + i; };
   const int HQ = 2 * g.Hs, WQ = 2 * g.Ws;
   const int kh = i16 >> 2, kw = i16 & 3;       // this lane's tap as a B-operand column
@@ -2034,6 +2057,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(WgradArgs g) {
       }
       if constexpr (PAIR) {
         pv[u][0] = mok ? __uint_as_float(reinterpret_cast<const unsigned*>(g.P)[m * 16 + i16]) : 0.f;   // (C1 == 32)
+      } else if constexpr (HALF) {
+        pv[u][0] = mok ? __uint_as_float(reinterpret_cast<const unsigned*>(g.P)[m * 8 + (i16 >> 1)]) : 0.f;   // (C1 == 16)
+        if (BNP) yv[u][0] = mok ? __uint_as_float(reinterpret_cast<const unsigned*>(g.p_y)[m * 8 + (i16 >> 1)]) : 0.f;
       } else {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
@@ -2055,11 +2081,15 @@ __global__ void __launch_bounds__(256) conv_wgrad_c1_kernel(WgradArgs g) {
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
         if (cb < ncb) {
+          auto half_of = [&](float raw) {       // this lane's bf16 of the dword it shares with its neighbour
+            const unsigned w = __float_as_uint(raw);
+            return __uint_as_float((i16 & 1) ? (w & 0xffff0000u) : (w << 16));
+          };
           float v = PAIR ? __uint_as_float(cb == 0 ? __float_as_uint(pv[u][0]) << 16 : __float_as_uint(pv[u][0]) & 0xffff0000u)
-                         : pv[u][cb];
+                    : HALF ? half_of(pv[u][0]) : pv[u][cb];
           if (mok && chan(cb, i16) < g.C1) {
             if (BNP) {
-              const float y = yv[u][cb], zz = fmaf(y, psc[cb], psh[cb]);
+              const float y = HALF ? half_of(yv[u][cb]) : yv[u][cb], zz = fmaf(y, psc[cb], psh[cb]);
               const float dz = zz > 0.f ? v : v * LRELU_SLOPE;
               v = fmaf(psc[cb], dz, fmaf(pca[cb], y, pcb[cb]));
             } else {
@@ -2746,9 +2776,10 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
   hipStream_t s = ST(stream);
   const bool wbf = dvae_mfma_precision() == DVAE_PRECISION_BF16;
   DVAE_REQUIRE(storage == 0 || (wbf && ((p.bm == -1 && storage == DVAE_ST_Y) ||
-                                        (p.bm == 0 && storage == DVAE_ST_X && C1 == 32 && g.p_y == nullptr))),
-               "conv4s2_wgrad: bf16 storage needs the bf16 MFMA mode and is only taken by the 64 x 32 row kernel (Q) "
-               "and the single-channel-Q kernel with 32 channels (P)");
+                                        (p.bm == 0 && storage == DVAE_ST_X && C1 == 32 && g.p_y == nullptr) ||
+                                        (p.bm == 0 && storage == (DVAE_ST_X | DVAE_ST_BNY) && C1 == 16 && g.p_y != nullptr))),
+               "conv4s2_wgrad: bf16 storage needs the bf16 MFMA mode and is only taken by the row kernels (Q) and the "
+               "single-channel-Q kernel (P with 32 channels; P and p_y with 16)");
   // a row-ring kernel in the variant of the current MFMA precision
 #define WG_BF(NAME, LDS, ...)                                                                           \
   {                                                                                                     \
@@ -2759,7 +2790,7 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
                                   aligned16(q_a) && aligned16(q_b) && aligned16(dx_out)),
                "conv4s2_wgrad: a BatchNorm-backward Q is only taken where dvae_conv4s2_wgrad_bnq_supported says so, "
                "with y, scale, shift, A, B and dx_out, 16-byte aligned");
-  if (C2 == 1) DVAE_WORK(((storage & DVAE_ST_X) ? 2.0 : 4.0) * (double)g.Mtot * C1 + 4.0 * (double)g.Mtot * 4, DVAE_UNIT_BYTE);       // streams P (and Q) once
+  if (C2 == 1) DVAE_WORK(((storage & DVAE_ST_X) ? 2.0 : 4.0) * (double)g.Mtot * C1 * (g.p_y ? 2 : 1) + 4.0 * (double)g.Mtot * 4, DVAE_UNIT_BYTE);       // streams P (and Q) once
   else DVAE_WORK(2.0 * (double)g.Mtot * C1 * 16 * C2, DVAE_UNIT_FLOP);
   if (p.bm == -3) {
     DVAE_REQUIRE((!p_scale || (aligned16(p_scale) && aligned16(p_shift))) && (!q_scale || (aligned16(q_scale) && aligned16(q_shift))),
@@ -2794,8 +2825,11 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
     if (g.st != 0) {                                                                                      \
       if (A == 64 && wbf && xp && !xq && g.st == DVAE_ST_Y)                                               \
         DVAE_LAUNCH((wgrad_rows_kernel<64, 32, 2, true, false, true, DVAE_ST_Y>), grid, dim3(256), ldsb, s, g); \
+      else if (A == 32 && wbf && !xp && xq && g.st == DVAE_ST_Y)                                          \
+        DVAE_LAUNCH((wgrad_rows_kernel<32, 16, 2, false, true, true, DVAE_ST_Y>), grid, dim3(256), ldsb, s, g); \
       else {                                                                                              \
-        dvae_set_error("conv4s2_wgrad: the 64 x 32 row kernel takes a bf16 Q (with a transformed P) in bf16 mode"); \
+        dvae_set_error("conv4s2_wgrad: the row kernels take a bf16 Q in bf16 mode (64 x 32 with a transformed P, " \
+                       "32 x 16 with a transformed Q)");                                                  \
         return -EINVAL;                                                                                   \
       }                                                                                                   \
     } else if (xp && xq) WG_BF(wgrad_rows_kernel, ldsb, A, B, 2, true, true) \
@@ -2809,7 +2843,9 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
   } else if (p.bm == 0) {
     const int ncb = (int)((C1 + 15) / 16);
     const dim3 grid((unsigned)p.split);
-    if (g.p_y != nullptr) {
+    if (g.p_y != nullptr && g.st != 0)             // (C1 == 16, P and p_y bf16: checked above)
+      DVAE_LAUNCH((conv_wgrad_c1_kernel<1, 8, true, DVAE_ST_X | DVAE_ST_BNY>), grid, dim3(256), 0, s, g);
+    else if (g.p_y != nullptr) {
       if (ncb <= 1) DVAE_LAUNCH((conv_wgrad_c1_kernel<1, 8, true>), grid, dim3(256), 0, s, g);
       else if (ncb <= 2) DVAE_LAUNCH((conv_wgrad_c1_kernel<2, 4, true>), grid, dim3(256), 0, s, g);
       else if (ncb <= 4) DVAE_LAUNCH((conv_wgrad_c1_kernel<4, 2, true>), grid, dim3(256), 0, s, g);
@@ -2883,10 +2919,11 @@ extern "C" int dvae_conv4s2_wgrad_bnq_f32(const float* P, const float* p_scale, 
 
 extern "C" int dvae_conv4s2_wgrad_bnp_f32(const float* du, const float* p_y, const float* p_scale, const float* p_shift,
                                           const float* p_a, const float* p_b, const float* Q, float* dw, float* ws,
-                                          int64_t N, int64_t Hs, int64_t Ws, int64_t C1, dvae_stream_t stream) {
+                                          int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int storage,
+                                          dvae_stream_t stream) {
   DVAE_REQUIRE(p_y != nullptr, "conv4s2_wgrad_bnp: p_y is null");
   return conv4s2_wgrad_impl(du, p_scale, p_shift, DVAE_ACT_NONE, Q, nullptr, nullptr, DVAE_ACT_NONE, dw, ws, N, Hs, Ws,
-                            C1, 1, p_y, p_a, p_b, stream);
+                            C1, 1, p_y, p_a, p_b, stream, nullptr, nullptr, nullptr, nullptr, storage);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -79,7 +79,7 @@ SIGNATURES = {
     'dvae_conv4s2_fwd_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P]),
     'dvae_deconv4s2_fwd_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P]),
     'dvae_conv_fwd_ws_floats': (L, [I, L, L, L, L, L]),
-    'dvae_conv4s2_fwd_ws_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P, L, P]),
+    'dvae_conv4s2_fwd_ws_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P, L, I, P]),
     'dvae_deconv4s2_fwd_ws_f32': (I, [P, P, P, I, P, P, P, L, L, L, L, L, P, L, I, P]),
     'dvae_conv4s2_dgrad_bnstat_f32': (I, [P, P, P, P, L, L, L, L, L, P, P, P, P, P, I, P]),
     'dvae_deconv4s2_dgrad_bnstat_f32': (I, [P, P, P, P, L, L, L, L, L, P, P, P, P, P, P]),
@@ -88,8 +88,8 @@ SIGNATURES = {
     'dvae_bn_bwd_reduce_rows': (L, [L, L]),
     'dvae_bn_bwd_reduce_f32': (I, [P, P, P, P, P, P, P, L, L, P]),
     'dvae_deconv4s2_bnin_supported': (I, [L, L, L, L]),
-    'dvae_deconv4s2_dgrad_bnstat_bnin_f32': (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P, P, P, P, P, P]),
-    'dvae_conv4s2_wgrad_bnp_f32': (I, [P, P, P, P, P, P, P, P, P, L, L, L, L, P]),
+    'dvae_deconv4s2_dgrad_bnstat_bnin_f32': (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P, P, P, P, P, I, P]),
+    'dvae_conv4s2_wgrad_bnp_f32': (I, [P, P, P, P, P, P, P, P, P, L, L, L, L, I, P]),
     'dvae_conv4s2_wgrad_bnq_supported': (I, [L, L, L, L, L]),
     'dvae_conv4s2_wgrad_bnq_f32': (I, [P, P, P, I, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P]),
     'dvae_conv4s2_bnin_supported': (I, [L, L, L, L]),

@@ -192,8 +192,14 @@ class EncoderConvs(torch.autograd.Function):
         packs = ops.pack_many([(w.detach(), False) for w in conv_w]
                               + ([(w.detach(), True) for w in conv_w[1:]] if need_bwd else []))
         ctx.wpd = [None] + packs[L:]
+        # bf16 mode, the few-channel encoder on full frames (1 -> 16 -> 32 channels from 64 x 64: the motion encoder):
+        # the first block's raw output, the largest tensor of this stack, and the gradient of its activation are
+        # kept as bfloat16; every kernel that touches them takes that
+        st16 = (need_bwd and ops.bf16_storage() and L == 2 and x.shape[1:] == (64, 64, 1)
+                and tuple(conv_w[0].shape[:2]) == (16, 1) and tuple(conv_w[1].shape[:2]) == (32, 16)
+                and bool(ops.lib.dvae_deconv4s2_bnin_supported(16, 16, 32, 16)))      # (backward's route)
         for l in range(L):
-            y, stats, nparts = ops.conv4s2_fwd(cur, sc, sh, act, packs[l], training)
+            y, stats, nparts = ops.conv4s2_fwd(cur, sc, sh, act, packs[l], training, out_bf16=st16 and l == 0)
             M = y.numel() // y.shape[-1]
             aff = _bn_affine(stats, nparts, M, gammas[l].detach(), betas[l].detach(), bns[l], training)
             ys.append(y)

@@ -554,18 +554,20 @@ def pack_many(items) -> list:
     return outs
 
 
-def conv4s2_fwd(x: Tensor, scale, shift, act: int, wp: Tensor, want_stats: bool):
-    """x [N,H,W,Cin] -> (y [N,H/2,W/2,Cout], stat partials or None, number of partial rows)."""
-    _chk(x, scale, shift, wp)
+def conv4s2_fwd(x: Tensor, scale, shift, act: int, wp: Tensor, want_stats: bool, out_bf16: bool = False):
+    """x [N,H,W,Cin] -> (y [N,H/2,W/2,Cout], stat partials or None, number of partial rows).  out_bf16: y is stored
+    as bfloat16 (single-channel-input kernel in bf16 mode; statistics from the fp32 accumulators)."""
+    _chk(scale, shift, wp)
+    _chk_st(x)
     N, H, W, Cin = x.shape
     Cout = wp.shape[0]
-    y = torch.empty(N, H // 2, W // 2, Cout, dtype=torch.float32, device=x.device)
+    y = torch.empty(N, H // 2, W // 2, Cout, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     nparts = lib.dvae_conv_stat_parts_written(N * (H // 2) * (W // 2), 1)
     stats = torch.empty(nparts, 2, Cout, dtype=torch.float32, device=x.device) if want_stats else None
     need = lib.dvae_conv_fwd_ws_floats(0, N, H, W, Cin, Cout)
     ws = workspace(need, x.device) if need else None
     check(lib.dvae_conv4s2_fwd_ws_f32(_p(x), _p(scale), _p(shift), act, _p(wp), _p(y), _p(stats), N, H, W, Cin, Cout,
-                                      _p(ws), need, _stream()), 'conv4s2_fwd')
+                                      _p(ws), need, _st(ST_X, x) | _st(ST_Y, y), _stream()), 'conv4s2_fwd')
     return y, stats, nparts
 
 
@@ -653,12 +655,13 @@ def deconv4s2_bnin_supported(x: Tensor, Cout: int) -> bool:
 def deconv4s2_dgrad_bnstat_bnin(du_in: Tensor, in_y: Tensor, in_aff, coef_a: Tensor, coef_b: Tensor, wp: Tensor,
                                 bn_y: Tensor, bn_aff):
     """deconv4s2_dgrad_bnstat on an input that still needs its own BatchNorm backward (see
-    conv4s2_dgrad_bnstat_bnin); returns (du, partials, dx)."""
-    _chk(du_in, in_y, wp, bn_y, coef_a, coef_b, *in_aff, *bn_aff)
+    conv4s2_dgrad_bnstat_bnin); returns (du, partials, dx).  A bfloat16 bn_y makes du bfloat16 too."""
+    _chk(du_in, in_y, wp, coef_a, coef_b, *in_aff, *bn_aff)
+    _chk_st(bn_y)
     assert du_in.shape == in_y.shape
     N, H, W, Cin = du_in.shape
     Cout = wp.shape[1]
-    y = torch.empty(N, 2 * H, 2 * W, Cout, dtype=torch.float32, device=du_in.device)
+    y = torch.empty(N, 2 * H, 2 * W, Cout, dtype=bn_y.dtype, device=du_in.device)
     assert bn_y.shape == y.shape
     dx = torch.empty_like(du_in)
     nparts = lib.dvae_conv_stat_parts_written(N * H * W, 4)
@@ -666,20 +669,23 @@ def deconv4s2_dgrad_bnstat_bnin(du_in: Tensor, in_y: Tensor, in_aff, coef_a: Ten
     sc, sh, mean, invstd = bn_aff
     check(lib.dvae_deconv4s2_dgrad_bnstat_bnin_f32(_p(du_in), _p(in_y), _p(in_aff[0]), _p(in_aff[1]), _p(coef_a),
                                                    _p(coef_b), _p(dx), _p(wp), _p(y), _p(stats), N, H, W, Cin, Cout,
-                                                   _p(bn_y), _p(sc), _p(sh), _p(mean), _p(invstd), _stream()),
+                                                   _p(bn_y), _p(sc), _p(sh), _p(mean), _p(invstd),
+                                                   _st(ST_Y, y) | _st(ST_BNY, bn_y), _stream()),
           'deconv4s2_dgrad_bnstat_bnin')
     return y, stats, dx
 
 
 def conv4s2_wgrad_bnp(du: Tensor, p_y: Tensor, p_aff, coef_a: Tensor, coef_b: Tensor, Q: Tensor) -> Tensor:
     """conv4s2_wgrad with a single-channel Q whose P = du still needs its layer's BatchNorm backward."""
-    _chk(du, p_y, Q, coef_a, coef_b, *p_aff)
+    _chk(Q, coef_a, coef_b, *p_aff)
+    _chk_st(du, p_y)
     N, Hs, Ws, C1 = du.shape
     assert du.shape == p_y.shape and Q.shape == (N, 2 * Hs, 2 * Ws, 1)
     dw = torch.empty(C1, 1, 4, 4, dtype=torch.float32, device=du.device)
     ws = workspace(lib.dvae_conv_wgrad_ws_floats(N, Hs, Ws, C1, 1), du.device)
     check(lib.dvae_conv4s2_wgrad_bnp_f32(_p(du), _p(p_y), _p(p_aff[0]), _p(p_aff[1]), _p(coef_a), _p(coef_b), _p(Q),
-                                         _p(dw), _p(ws), N, Hs, Ws, C1, _stream()), 'conv4s2_wgrad_bnp')
+                                         _p(dw), _p(ws), N, Hs, Ws, C1, _st(ST_X, du) | _st(ST_BNY, p_y), _stream()),
+          'conv4s2_wgrad_bnp')
     return dw
 
 

@@ -299,7 +299,8 @@ int dvae_deconv4s2_fwd_f32(const float* x, const float* in_scale, const float* i
 int64_t dvae_conv_fwd_ws_floats(int transposed, int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout);
 int dvae_conv4s2_fwd_ws_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
                             const float* wp, float* y, float* stat_partials, int64_t N, int64_t H, int64_t W,
-                            int64_t Cin, int64_t Cout, float* ws, int64_t ws_floats, dvae_stream_t stream);
+                            int64_t Cin, int64_t Cout, float* ws, int64_t ws_floats, int storage,
+                            dvae_stream_t stream);
 int dvae_deconv4s2_fwd_ws_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,
                               const float* wp, float* y, float* stat_partials, int64_t N, int64_t H, int64_t W,
                               int64_t Cin, int64_t Cout, float* ws, int64_t ws_floats, int storage,
@@ -309,14 +310,20 @@ int dvae_deconv4s2_fwd_ws_f32(const float* x, const float* in_scale, const float
  * HBM-bound kernels around them.  A set bit says that the tensor it names holds bfloat16 elements (same shape and
  * element order; its pointer keeps the float type of the signature): DVAE_ST_X the input x (weight gradients: P),
  * DVAE_ST_Y the output y (weight gradients: Q), DVAE_ST_BNY bn_y (p_y), DVAE_ST_INY in_y, DVAE_ST_DX dx_out.
- * Only in bf16 mode, and only the combinations that a training step of the decoder's last block (64 -> 32 channels
- * on 16 x 16, then 32 -> 1) produces have kernels, -EINVAL otherwise:
+ * Only in bf16 mode, and only the combinations that a training step produces have kernels, -EINVAL otherwise.
+ * Decoder's last block (64 -> 32 channels on 16 x 16, then 32 -> 1; its raw output, du and dL/dy are bf16):
  *   dvae_deconv4s2_fwd_ws_f32           64 -> 32 row kernel, no fused statistics of a layer below:  DVAE_ST_Y
  *   dvae_deconv4s2_final_fwd_f32        Cin = 32:                                                   DVAE_ST_X
  *   dvae_conv4s2_wgrad_f32              single-channel Q, C1 = 32:                                  DVAE_ST_X
  *                                       64 x 32 row kernel with a transformed P:                    DVAE_ST_Y
  *   dvae_conv4s2_dgrad_bnstat_f32       Cin = 1, Cout = 32:                               DVAE_ST_Y | DVAE_ST_BNY
  *   dvae_conv4s2_dgrad_bnstat_bnin_f32  32 -> 64 row kernel:                   DVAE_ST_X | DVAE_ST_INY | DVAE_ST_DX
+ * Few-channel encoder's first block (1 -> 16 channels on 64 x 64, then 16 -> 32; its raw output and du are bf16):
+ *   dvae_conv4s2_fwd_ws_f32             Cin = 1, Cout <= 16, no fused statistics:                   DVAE_ST_Y
+ *                                       16 -> 32 row kernel with a load transform:                  DVAE_ST_X
+ *   dvae_conv4s2_wgrad_f32              32 x 16 row kernel with a transformed Q:                    DVAE_ST_Y
+ *   dvae_deconv4s2_dgrad_bnstat_bnin_f32  32 -> 16 row kernel:                            DVAE_ST_Y | DVAE_ST_BNY
+ *   dvae_conv4s2_wgrad_bnp_f32          C1 = 16:                                          DVAE_ST_X | DVAE_ST_BNY
  * What a kernel writes as bfloat16 is the round-to-nearest-even of the fp32 value it would have written; statistics
  * are always reduced from the fp32 accumulators, before rounding.  No counterpart in the reference. */
 #define DVAE_ST_X 1
@@ -359,7 +366,8 @@ int dvae_deconv4s2_dgrad_bnstat_bnin_f32(const float* du_in, const float* in_y, 
                                          float* dx_out, const float* wp, float* y, float* stat_partials,
                                          int64_t N, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                                          const float* bn_y, const float* bn_scale, const float* bn_shift,
-                                         const float* bn_mean, const float* bn_invstd, dvae_stream_t stream);
+                                         const float* bn_mean, const float* bn_invstd, int storage,
+                                         dvae_stream_t stream);
 int dvae_deconv4s2_dgrad_bnstat_f32(const float* x, const float* wp, float* y, float* stat_partials, int64_t N,
                                     int64_t H, int64_t W, int64_t Cin, int64_t Cout, const float* bn_y,
                                     const float* bn_scale, const float* bn_shift, const float* bn_mean,
@@ -382,7 +390,7 @@ int dvae_conv4s2_wgrad_f32(const float* P, const float* p_scale, const float* p_
  * dvae_conv4s2_wgrad_f32 with C2 = 1. */
 int dvae_conv4s2_wgrad_bnp_f32(const float* du, const float* p_y, const float* p_scale, const float* p_shift,
                                const float* p_a, const float* p_b, const float* Q, float* dw, float* ws,
-                               int64_t N, int64_t Hs, int64_t Ws, int64_t C1, dvae_stream_t stream);
+                               int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int storage, dvae_stream_t stream);
 /* dvae_conv4s2_wgrad_f32 whose Q = dL/d(activation) has not been through its layer's BatchNorm backward
  * (weight gradient of a decoder block, models/decoders.py:40-45): du, the layer's raw output q_y, its
  * forward affine and the vectors of dvae_bn_bwd_coeffs_f32.  Q becomes scale*dz + A*y + B as it is
