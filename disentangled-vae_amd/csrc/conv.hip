@@ -922,8 +922,10 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows_kernel(ConvArgs
 // output channels each ([16][4 taps][Cin] = 128 registers per lane at Cin = 128).  A group of sixteen
 // pixels is two rows of eight, so the row a lane reads depends on the lane: rows outside the frame are
 // redirected to a ninth, all-zero slot instead of being skipped.
-template <int CIN, int WAVES_PER_EU, bool XF, bool BNS, bool BF>
+template <int CIN, int WAVES_PER_EU, bool XF, bool BNS, bool BF, int ST = 0>
 __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows8_kernel(ConvArgs g) {
+  static_assert(BF || ST == 0, "bf16 storage goes with bf16 MFMA operands");
+  static_assert((ST & ~DVAE_ST_Y) == 0, "this kernel only writes bf16");
   typedef RowOps<BF> R;
   typedef typename R::frag frag_t;
   constexpr int COUT = 64, W = 8, NU = CIN / 16;
@@ -1057,7 +1059,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) deconv_rows8_kernel(ConvArg
     }
     // D: row = output channel 16 wave + 4kq + e, column = pixel i16
     const f32x4 v = acc[0] + acc[1];
-    *reinterpret_cast<f32x4*>(g.y + orow * COUT + 16 * wave + 4 * kq) = v;
+    st4s(g.y, orow * COUT + 16 * wave + 4 * kq, v, (ST & DVAE_ST_Y) != 0);
     if (!BNS) {
       s1 += v;
       s2 += v * v;
@@ -1373,6 +1375,12 @@ static bool launch_deconv_rows_st(const ConvArgs& g, dim3 grid, hipStream_t stre
       DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, XF, BNS, BNIN, true, DVAE_ST_Y>), grid, dim3(256), 0, stream, g);
       return true;
     }
+    // ... and reads the block before it as bf16
+    if (XF && g.st == (DVAE_ST_X | DVAE_ST_Y)) {
+      DVAE_LAUNCH((deconv_rows_kernel<CI, CO, WPE, true, BNS, BNIN, true, DVAE_ST_X | DVAE_ST_Y>), grid, dim3(256), 0,
+                  stream, g);
+      return true;
+    }
   }
   if constexpr (CI == 32 && CO == 16 && BNS && BNIN) {
     // data gradient of the motion encoder's second convolution: reads the first layer's raw output (bf16) for the
@@ -1392,6 +1400,12 @@ static bool launch_conv_rows_st(const ConvArgs& g, dim3 grid, size_t lds, hipStr
     if (g.st == (DVAE_ST_X | DVAE_ST_INY | DVAE_ST_DX)) {
       DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, XF, BNS, BNIN, true, DVAE_ST_X | DVAE_ST_INY | DVAE_ST_DX>), grid,
                   dim3(CO * 4), lds, stream, g);
+      return true;
+    }
+    // ... with the block below stored as bf16 too (its raw output read for the sums, the gradient of its activation written)
+    constexpr int ALL = DVAE_ST_X | DVAE_ST_INY | DVAE_ST_DX | DVAE_ST_BNY | DVAE_ST_Y;
+    if (g.st == ALL) {
+      DVAE_LAUNCH((conv_rows_kernel<CI, CO, WPE, XF, BNS, BNIN, true, ALL>), grid, dim3(CO * 4), lds, stream, g);
       return true;
     }
   }
@@ -1488,11 +1502,6 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     dvae_set_error("%s: no kernel takes a BatchNorm-backward input at this shape (see dvae_deconv4s2_bnin_supported)", name);
     return -EINVAL;
   }
-  if (MODE == 1 && g.st != 0) {
-    dvae_set_error("%s: bf16 storage is only taken by the few-channel row kernels (64 -> 32 and 32 -> 16 channels on "
-                   "frames 16 to 32 pixels wide)", name);
-    return -EINVAL;
-  }
   if (MODE == 1 && g.Cin == 128 && g.Cout == 64 && g.W == 8 && g.H >= 2 && aligned16(g.y) &&
       (!bns || aligned16(g.bn_y)) && (!g.in_scale || (aligned16(g.in_scale) && aligned16(g.in_shift)))) {
     const unsigned gx = (unsigned)(conv_parts_written(g.M, phases) / phases);
@@ -1502,7 +1511,14 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     DVAE_WORK(2.0 * (double)g.M * phases * g.Cout * g.K, DVAE_UNIT_FLOP);
 #define ROWS8_K(XF_, BNS_)                                                                              \
   {                                                                                                     \
-    if (bf) DVAE_LAUNCH((deconv_rows8_kernel<128, 2, XF_, BNS_, true>), grid, dim3(256), 0, stream, g); \
+    if (bf && g.st != 0) {                                                                              \
+      if (XF_ && !(BNS_) && g.st == DVAE_ST_Y)                                                          \
+        DVAE_LAUNCH((deconv_rows8_kernel<128, 2, true, false, true, DVAE_ST_Y>), grid, dim3(256), 0, stream, g); \
+      else {                                                                                            \
+        dvae_set_error("%s: the 128 -> 64 row kernel writes a bf16 output in its plain forward form only", name); \
+        return -EINVAL;                                                                                 \
+      }                                                                                                 \
+    } else if (bf) DVAE_LAUNCH((deconv_rows8_kernel<128, 2, XF_, BNS_, true>), grid, dim3(256), 0, stream, g); \
     else DVAE_LAUNCH((deconv_rows8_kernel<128, 2, XF_, BNS_, false>), grid, dim3(256), 0, stream, g);   \
   }
     if (bns && xf) ROWS8_K(true, true)
@@ -1512,6 +1528,11 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
 #undef ROWS8_K
     DVAE_LAUNCH_CHECK(name);
     return 0;
+  }
+  if (MODE == 1 && g.st != 0) {
+    dvae_set_error("%s: bf16 storage is only taken by the row kernels (64 -> 32 and 32 -> 16 channels on frames 16 to "
+                   "32 pixels wide, 128 -> 64 on 8-pixel-wide frames)", name);
+    return -EINVAL;
   }
 #define CROWS_K(CI, CO, WPE, XF_, BNS_, BNIN_)                                                           \
   {                                                                                                      \
@@ -2367,8 +2388,11 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) wgrad_rows_kernel(WgradArgs
 // layer's raw output; a row becomes scale*dz + A*y + B on its way into LDS).  Every Q row is met by
 // exactly two filter rows; the workgroups of filter rows 1 and 2 between them meet each row once and
 // write the finished rows to dx_out for the data-gradient kernel.
-template <bool XP, bool XQ, bool BNQ, bool BF>
+template <bool XP, bool XQ, bool BNQ, bool BF, int ST = 0>
 __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
+  static_assert(BF || ST == 0, "bf16 storage goes with bf16 MFMA operands");
+  static_assert(ST == 0 || (BNQ && ST == (DVAE_ST_Y | DVAE_ST_INY)), "bf16 storage: Q and q_y of the BatchNorm-backward form");
+  constexpr bool qbf = (ST & DVAE_ST_Y) != 0, qybf = (ST & DVAE_ST_INY) != 0;
   constexpr int C1 = 128, C2 = 64, Ws = 8, WQ = 16, NCB = C2 / 16;
   constexpr int PSP = C1 + 4, PSQ = C2 + 2, P4 = C1 / 4, Q4 = C2 / 4;
   constexpr int PROW = Ws * PSP, QROW = (WQ + 2) * PSQ;
@@ -2448,8 +2472,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
       raw.qok[h] = pok && hin >= 0 && hin < 2 * Hs;
       raw.p[h] = ldg4(g.P + (pok ? prow * (int64_t)(Ws * C1) : 0) + 4 * threadIdx.x);
       raw.qoff[h] = (raw.qok[h] ? (2 * prow - 1 + dh) * (int64_t)(WQ * C2) : 0) + 4 * threadIdx.x;
-      raw.q[h] = ldg4(g.Q + raw.qoff[h]);
-      if (BNQ) raw.qy[h] = ldg4(g.q_y + raw.qoff[h]);
+      raw.q[h] = ld4s(g.Q, raw.qoff[h], qbf);
+      if (BNQ) raw.qy[h] = ld4s(g.q_y, raw.qoff[h], qybf);
     }
   };
   auto deposit = [&](int64_t p, const Raw& raw) {
@@ -2457,9 +2481,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
     for (int h = 0; h < 2; ++h) {
       const f32x4 pv = XP ? transform(raw.p[h], psc, psh, pslope) : raw.p[h];
       *reinterpret_cast<f32x4*>(&pbuf[p & 1][h][(threadIdx.x / P4) * PSP + 4 * lp4]) = pv;
-      f32x4 qv = XQ ? transform(raw.q[h], qsc, qsh, qslope) : raw.q[h];
+      f32x4 qv = XQ ? transform(raw.q[h], qsc, qsh, qslope) : widen4s(raw.q[h], qbf);
       if (BNQ) {
-        const f32x4 y = raw.qy[h];
+        const f32x4 y = widen4s(raw.qy[h], qybf);
         const f32x4 zz = y * qsc + qsh;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -2775,7 +2799,8 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
   g.ktiles_per_split = p.ktiles_per_split;
   hipStream_t s = ST(stream);
   const bool wbf = dvae_mfma_precision() == DVAE_PRECISION_BF16;
-  DVAE_REQUIRE(storage == 0 || (wbf && ((p.bm == -1 && storage == DVAE_ST_Y) ||
+  DVAE_REQUIRE(storage == 0 || (wbf && ((p.bm == -1 && (storage == DVAE_ST_Y || storage == (DVAE_ST_X | DVAE_ST_Y))) ||
+                                        (p.bm == -2 && storage == (DVAE_ST_Y | DVAE_ST_INY) && g.q_y != nullptr) ||
                                         (p.bm == 0 && storage == DVAE_ST_X && C1 == 32 && g.p_y == nullptr) ||
                                         (p.bm == 0 && storage == (DVAE_ST_X | DVAE_ST_BNY) && C1 == 16 && g.p_y != nullptr))),
                "conv4s2_wgrad: bf16 storage needs the bf16 MFMA mode and is only taken by the row kernels (Q) and the "
@@ -2807,7 +2832,10 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
                  "conv4s2_wgrad: scale/shift vectors must be 16-byte aligned");
     const dim3 grid((unsigned)p.split * 4);
     const bool xp = p_scale != nullptr || p_act != DVAE_ACT_NONE, xq = q_scale != nullptr || q_act != DVAE_ACT_NONE;
-    if (g.q_y != nullptr) {
+    if (g.q_y != nullptr && g.st != 0) {           // (bf16 mode, Q and q_y: checked above)
+      if (xp) DVAE_LAUNCH((wgrad_rows8_kernel<true, false, true, true, DVAE_ST_Y | DVAE_ST_INY>), grid, dim3(256), 0, s, g);
+      else DVAE_LAUNCH((wgrad_rows8_kernel<false, false, true, true, DVAE_ST_Y | DVAE_ST_INY>), grid, dim3(256), 0, s, g);
+    } else if (g.q_y != nullptr) {
       if (xp) WG_BF(wgrad_rows8_kernel, 0, true, false, true)
       else WG_BF(wgrad_rows8_kernel, 0, false, false, true)
     } else if (xp && xq) WG_BF(wgrad_rows8_kernel, 0, true, true, false)
@@ -2825,6 +2853,8 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
     if (g.st != 0) {                                                                                      \
       if (A == 64 && wbf && xp && !xq && g.st == DVAE_ST_Y)                                               \
         DVAE_LAUNCH((wgrad_rows_kernel<64, 32, 2, true, false, true, DVAE_ST_Y>), grid, dim3(256), ldsb, s, g); \
+      else if (A == 64 && wbf && xp && !xq && g.st == (DVAE_ST_X | DVAE_ST_Y))                            \
+        DVAE_LAUNCH((wgrad_rows_kernel<64, 32, 2, true, false, true, DVAE_ST_X | DVAE_ST_Y>), grid, dim3(256), ldsb, s, g); \
       else if (A == 32 && wbf && !xp && xq && g.st == DVAE_ST_Y)                                          \
         DVAE_LAUNCH((wgrad_rows_kernel<32, 16, 2, false, true, true, DVAE_ST_Y>), grid, dim3(256), ldsb, s, g); \
       else {                                                                                              \
@@ -2911,10 +2941,10 @@ extern "C" int dvae_conv4s2_wgrad_bnq_f32(const float* P, const float* p_scale, 
                                           const float* du, const float* q_y, const float* q_scale,
                                           const float* q_shift, const float* q_a, const float* q_b, float* dx_out,
                                           float* dw, float* ws, int64_t N, int64_t Hs, int64_t Ws, int64_t C1,
-                                          int64_t C2, dvae_stream_t stream) {
+                                          int64_t C2, int storage, dvae_stream_t stream) {
   DVAE_REQUIRE(q_y != nullptr, "conv4s2_wgrad_bnq: q_y is null");
   return conv4s2_wgrad_impl(P, p_scale, p_shift, p_act, du, q_scale, q_shift, DVAE_ACT_NONE, dw, ws, N, Hs, Ws, C1, C2,
-                            nullptr, nullptr, nullptr, stream, q_y, q_a, q_b, dx_out);
+                            nullptr, nullptr, nullptr, stream, q_y, q_a, q_b, dx_out, storage);
 }
 
 extern "C" int dvae_conv4s2_wgrad_bnp_f32(const float* du, const float* p_y, const float* p_scale, const float* p_shift,

@@ -91,7 +91,7 @@ SIGNATURES = {
     'dvae_deconv4s2_dgrad_bnstat_bnin_f32': (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P, P, P, P, P, I, P]),
     'dvae_conv4s2_wgrad_bnp_f32': (I, [P, P, P, P, P, P, P, P, P, L, L, L, L, I, P]),
     'dvae_conv4s2_wgrad_bnq_supported': (I, [L, L, L, L, L]),
-    'dvae_conv4s2_wgrad_bnq_f32': (I, [P, P, P, I, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P]),
+    'dvae_conv4s2_wgrad_bnq_f32': (I, [P, P, P, I, P, P, P, P, P, P, P, P, P, L, L, L, L, L, I, P]),
     'dvae_conv4s2_bnin_supported': (I, [L, L, L, L]),
     'dvae_conv4s2_dgrad_bnstat_bnin_f32': (I, [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, P, P, P, P, P, I, P]),
     'dvae_conv_wgrad_ws_floats': (L, [L, L, L, L, L]),

@@ -443,8 +443,13 @@ class DecoderCNN(torch.autograd.Function):
                 and 4 * 2 ** (L - 1) == 16 and replicas == 1
                 and bool(ops.lib.dvae_conv4s2_bnin_supported(32, 32, 32, 64)))   # (backward's route for this block)
         ctx.st16 = st16
+        # ... and, where the block before it is the 128 -> 64 one on 8 x 8 frames (whose backward takes the route of
+        # the weight-gradient kernel that folds the BatchNorm backward in), that block's raw output and du as well
+        st16b = (st16 and L >= 3 and tuple(dec_w[-2].shape[:2]) == (128, 64)
+                 and bool(ops.lib.dvae_conv4s2_wgrad_bnq_supported(N, 8, 8, 128, 64)))
         for l in range(L):
-            y, stats, nparts = ops.deconv4s2_fwd(cur, sc, sh, act, packs[l], training, out_bf16=st16 and l == L - 1)
+            y, stats, nparts = ops.deconv4s2_fwd(cur, sc, sh, act, packs[l], training,
+                                                 out_bf16=(st16 and l == L - 1) or (st16b and l == L - 2))
             M = y.numel() // y.shape[-1]
             aff = _bn_affine(stats, nparts, M, gammas[l].detach(), betas[l].detach(), bns[l], training, replicas)
             ys.append(y)

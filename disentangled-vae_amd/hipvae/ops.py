@@ -698,16 +698,17 @@ def conv4s2_wgrad_bnq(P: Tensor, p_scale, p_shift, p_act: int, du: Tensor, q_y: 
                       coef_b: Tensor):
     """conv4s2_wgrad whose Q = du still needs its layer's BatchNorm backward; returns (dw, dx) with dx the
     finished dL/d(q_y)."""
-    _chk(P, p_scale, p_shift, du, q_y, coef_a, coef_b, *q_aff)
+    _chk(P, p_scale, p_shift, coef_a, coef_b, *q_aff)
+    _chk_st(du, q_y)
     N, Hs, Ws, C1 = P.shape
     C2 = du.shape[3]
     assert du.shape == q_y.shape == (N, 2 * Hs, 2 * Ws, C2)
     dw = torch.empty(C1, C2, 4, 4, dtype=torch.float32, device=P.device)
-    dx = torch.empty_like(du)
+    dx = torch.empty(du.shape, dtype=torch.float32, device=du.device)        # (always floats: a tiled kernel reads it)
     ws = workspace(lib.dvae_conv_wgrad_ws_floats(N, Hs, Ws, C1, C2), P.device)
     check(lib.dvae_conv4s2_wgrad_bnq_f32(_p(P), _p(p_scale), _p(p_shift), p_act, _p(du), _p(q_y), _p(q_aff[0]),
                                          _p(q_aff[1]), _p(coef_a), _p(coef_b), _p(dx), _p(dw), _p(ws), N, Hs, Ws, C1,
-                                         C2, _stream()), 'conv4s2_wgrad_bnq')
+                                         C2, _st(ST_Y, du) | _st(ST_INY, q_y), _stream()), 'conv4s2_wgrad_bnq')
     return dw, dx
 
 
@@ -721,12 +722,12 @@ def conv4s2_dgrad_bnstat_bnin(du_in: Tensor, in_y: Tensor, in_aff, coef_a: Tenso
     """conv4s2_dgrad_bnstat on an input that still needs its own BatchNorm backward: du_in is the gradient
     of the activation of the layer whose raw output is in_y; returns (du, partials, dx) where dx is the
     finished dL/d(in_y) (for the weight-gradient call)."""
-    _chk(wp, bn_y, coef_a, coef_b, *in_aff, *bn_aff)
-    _chk_st(du_in, in_y)
+    _chk(wp, coef_a, coef_b, *in_aff, *bn_aff)
+    _chk_st(du_in, in_y, bn_y)
     assert du_in.shape == in_y.shape
     N, H, W, Cin = du_in.shape
     Cout = wp.shape[0]
-    y = torch.empty(N, H // 2, W // 2, Cout, dtype=torch.float32, device=du_in.device)
+    y = torch.empty(N, H // 2, W // 2, Cout, dtype=bn_y.dtype, device=du_in.device)      # (bfloat16 when bn_y is)
     assert bn_y.shape == y.shape
     dx = torch.empty_like(du_in)                # (bfloat16 when du_in is)
     nparts = lib.dvae_conv_stat_parts_written(N * (H // 2) * (W // 2), 1)
@@ -735,7 +736,8 @@ def conv4s2_dgrad_bnstat_bnin(du_in: Tensor, in_y: Tensor, in_aff, coef_a: Tenso
     check(lib.dvae_conv4s2_dgrad_bnstat_bnin_f32(_p(du_in), _p(in_y), _p(in_aff[0]), _p(in_aff[1]), _p(coef_a),
                                                  _p(coef_b), _p(dx), _p(wp), _p(y), _p(stats), N, H, W, Cin, Cout,
                                                  _p(bn_y), _p(sc), _p(sh), _p(mean), _p(invstd),
-                                                 _st(ST_X, du_in) | _st(ST_INY, in_y) | _st(ST_DX, dx), _stream()),
+                                                 _st(ST_X, du_in) | _st(ST_INY, in_y) | _st(ST_DX, dx)
+                                                 | _st(ST_BNY, bn_y) | _st(ST_Y, y), _stream()),
           'conv4s2_dgrad_bnstat_bnin')
     return y, stats, dx
 

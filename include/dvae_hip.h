@@ -318,6 +318,12 @@ int dvae_deconv4s2_fwd_ws_f32(const float* x, const float* in_scale, const float
  *                                       64 x 32 row kernel with a transformed P:                    DVAE_ST_Y
  *   dvae_conv4s2_dgrad_bnstat_f32       Cin = 1, Cout = 32:                               DVAE_ST_Y | DVAE_ST_BNY
  *   dvae_conv4s2_dgrad_bnstat_bnin_f32  32 -> 64 row kernel:                   DVAE_ST_X | DVAE_ST_INY | DVAE_ST_DX
+ * ... together with the block before it (128 -> 64 channels on 8 x 8; its raw output and du are bf16):
+ *   dvae_deconv4s2_fwd_ws_f32           128 -> 64 row kernel, load transform, no fused statistics:  DVAE_ST_Y
+ *                                       64 -> 32 row kernel, load transform:                   DVAE_ST_X | DVAE_ST_Y
+ *   dvae_conv4s2_wgrad_f32              64 x 32 row kernel with a transformed P:                DVAE_ST_X | DVAE_ST_Y
+ *   dvae_conv4s2_dgrad_bnstat_bnin_f32  32 -> 64 row kernel: DVAE_ST_X | DVAE_ST_INY | DVAE_ST_DX | DVAE_ST_BNY | DVAE_ST_Y
+ *   dvae_conv4s2_wgrad_bnq_f32          128 x 64 row kernel (Q = du: DVAE_ST_Y, q_y: DVAE_ST_INY):  DVAE_ST_Y | DVAE_ST_INY
  * Few-channel encoder's first block (1 -> 16 channels on 64 x 64, then 16 -> 32; its raw output and du are bf16):
  *   dvae_conv4s2_fwd_ws_f32             Cin = 1, Cout <= 16, no fused statistics:                   DVAE_ST_Y
  *                                       16 -> 32 row kernel with a load transform:                  DVAE_ST_X
@@ -400,7 +406,8 @@ int dvae_conv4s2_wgrad_bnq_supported(int64_t N, int64_t Hs, int64_t Ws, int64_t 
 int dvae_conv4s2_wgrad_bnq_f32(const float* P, const float* p_scale, const float* p_shift, int p_act,
                                const float* du, const float* q_y, const float* q_scale, const float* q_shift,
                                const float* q_a, const float* q_b, float* dx_out, float* dw, float* ws,
-                               int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2, dvae_stream_t stream);
+                               int64_t N, int64_t Hs, int64_t Ws, int64_t C1, int64_t C2, int storage,
+                               dvae_stream_t stream);
 /* Final decoder layer (models/decoders.py:49-53,67-68): ConvTranspose2d(Cin -> 1, bias) + sigmoid.
  * x [N,H,W,Cin] (+ load-time transform), w torch layout [Cin][1][4][4], y [N,2H,2W]. Cin%4==0. */
 int dvae_deconv4s2_final_fwd_f32(const float* x, const float* in_scale, const float* in_shift, int in_act,

@@ -96,6 +96,48 @@ def test_last_block_backward_on_bf16(ops, N):
 
 
 @pytest.mark.parametrize('N', [3, 70])
+def test_decoder_64_channel_block_on_bf16(ops, N):
+    """128 -> 64 on 8 x 8 written as bf16; read by the 64 -> 32 block (forward, weight gradient, BatchNorm-backward sums
+    of its data gradient, which then writes a bf16 du) and by the 128 x 64 weight gradient that folds the BatchNorm
+    backward of that du in"""
+    x = rnd(N, 8, 8, 128, seed=80)
+    sc, sh, _, _ = aff_of(128, 81)
+    wp = ops.pack_deconv_w(rnd(128, 64, 4, 4, seed=85, scale=0.1))
+    y32, s32, n32 = ops.deconv4s2_fwd(x, sc, sh, ops.ACT_LRELU, wp, True)
+    y16, s16, n16 = ops.deconv4s2_fwd(x, sc, sh, ops.ACT_LRELU, wp, True, out_bf16=True)
+    assert y16.dtype == torch.bfloat16 and n16 == n32
+    assert torch.equal(y16, y32.bfloat16()) and torch.equal(s16, s32)
+    # forward of the next block: bf16 in, bf16 out
+    aff3 = aff_of(64, 86)
+    wp2 = ops.pack_deconv_w(rnd(64, 32, 4, 4, seed=90, scale=0.2))
+    a, sa, _ = ops.deconv4s2_fwd(y16, aff3[0], aff3[1], ops.ACT_LRELU, wp2, True, out_bf16=True)
+    b, sb, _ = ops.deconv4s2_fwd(y16.float(), aff3[0], aff3[1], ops.ACT_LRELU, wp2, True, out_bf16=True)
+    assert torch.equal(a, b) and torch.equal(sa, sb)
+    # its weight gradient: bf16 P and bf16 Q
+    dy6 = rnd(N, 32, 32, 32, seed=91).bfloat16()
+    dw16 = ops.conv4s2_wgrad(y16, aff3[0], aff3[1], ops.ACT_LRELU, dy6, None, None, ops.ACT_NONE)
+    dw32 = ops.conv4s2_wgrad(y16.float(), aff3[0], aff3[1], ops.ACT_LRELU, dy6, None, None, ops.ACT_NONE)
+    assert torch.equal(dw16, dw32)
+    # its data gradient: everything bf16
+    du6 = rnd(N, 32, 32, 32, seed=92).bfloat16()
+    y6 = rnd(N, 32, 32, 32, seed=93).bfloat16()
+    aff6 = aff_of(32, 94)
+    ca, cb = 0.01 * rnd(32, seed=98), 0.01 * rnd(32, seed=99)
+    wpc = ops.pack_conv_w(rnd(64, 32, 4, 4, seed=100, scale=0.2))
+    g_du, g_parts, g_dx = ops.conv4s2_dgrad_bnstat_bnin(du6, y6, aff6, ca, cb, wpc, y16, aff3)
+    r_du, r_parts, r_dx = ops.conv4s2_dgrad_bnstat_bnin(du6, y6, aff6, ca, cb, wpc, y16.float(), aff3)
+    assert g_du.dtype == torch.bfloat16 and r_du.dtype == torch.float32
+    assert torch.equal(g_du, r_du.bfloat16()) and torch.equal(g_parts, r_parts) and torch.equal(g_dx, r_dx)
+    # weight gradient of the 128 -> 64 block on that du and y
+    assert ops.conv4s2_wgrad_bnq_supported(x, 64)
+    ca3, cb3 = 0.01 * rnd(64, seed=101), 0.01 * rnd(64, seed=102)
+    dwa, dxa = ops.conv4s2_wgrad_bnq(x, sc, sh, ops.ACT_LRELU, g_du, y16, aff3, ca3, cb3)
+    dwb, dxb = ops.conv4s2_wgrad_bnq(x, sc, sh, ops.ACT_LRELU, g_du.float(), y16.float(), aff3, ca3, cb3)
+    assert dxa.dtype == torch.float32
+    assert torch.equal(dwa, dwb) and torch.equal(dxa, dxb)
+
+
+@pytest.mark.parametrize('N', [3, 70])
 def test_few_channel_encoder_forward_on_bf16(ops, N):
     """1 -> 16 channels written as bf16, 16 -> 32 reading it"""
     x = rnd(N, 64, 64, 1, seed=50).abs()
@@ -142,11 +184,11 @@ def test_bf16_tensors_are_refused_where_no_kernel_takes_them(ops):
     wp = ops.pack_deconv_w(rnd(256, 128, 4, 4, seed=41, scale=0.1))
     with pytest.raises(RuntimeError):
         ops.deconv4s2_fwd(x, None, None, ops.ACT_NONE, wp, False)
-    # the 64 -> 32 row kernel writes bf16 but has no variant that also reads it, nor does the 64-channel final layer
+    # the 64 -> 32 row kernel reads bf16 only where it also writes it, and the 64-channel final layer not at all
     x = rnd(3, 16, 16, 64, seed=44).bfloat16()
     wp = ops.pack_deconv_w(rnd(64, 32, 4, 4, seed=45, scale=0.1))
     with pytest.raises(RuntimeError):
-        ops.deconv4s2_fwd(x, None, None, ops.ACT_NONE, wp, False, out_bf16=True)
+        ops.deconv4s2_fwd(x, None, None, ops.ACT_NONE, wp, False)
     with pytest.raises(RuntimeError):
         ops.deconv4s2_final_fwd(x, None, None, ops.ACT_NONE, rnd(64, 1, 4, 4, seed=46), rnd(1, seed=47), ops.ACT_SIGMOID)
     ops.set_precision('fp32')
