@@ -698,6 +698,28 @@ __device__ __forceinline__ s16x4 bf_quad(float k0, float k1, float k2, float k3)
   return __builtin_bit_cast(s16x4, w);
 }
 
+// The weight-gradient row kernels in the 'fp32_split' mode: both operands of a product come out of LDS as fp32
+// quads (a lane's four pixels of one channel), so a lane splits each quad into its three bf16 terms there and
+// issues the six largest of the nine cross products on the bf16 MFMA, smallest first (gemm_core.h: split_pair).
+// Products with one accumulator are six dependent MFMAs; callers run a term over all their accumulators before
+// the next term.
+struct SplitQuad {
+  s16x4 t[3];      // hi, mid, lo
+};
+__device__ __forceinline__ SplitQuad split_quad(float k0, float k1, float k2, float k3) {
+  uint32_t h0, m0, l0, h1, m1, l1;
+  split_pair(k0, k1, h0, m0, l0);
+  split_pair(k2, k3, h1, m1, l1);
+  SplitQuad q;
+  q.t[0] = __builtin_bit_cast(s16x4, make_uint2(h0, h1));
+  q.t[1] = __builtin_bit_cast(s16x4, make_uint2(m0, m1));
+  q.t[2] = __builtin_bit_cast(s16x4, make_uint2(l0, l1));
+  return q;
+}
+// term pairs (a, b) of the six products, smallest first
+__device__ constexpr int SPLIT_TA[6] = {2, 0, 1, 1, 0, 0};
+__device__ constexpr int SPLIT_TB[6] = {0, 2, 1, 0, 1, 0};
+
 // Transposed convolution with few channels (Cin*Cout <= 2048) on frames at least sixteen pixels wide:
 // too little work per pixel for a tiled GEMM whose K loop is four taps deep.  A workgroup is four waves
 // = the four sub-pixel phases; each wave keeps its phase's whole filter [Cout][4 taps][Cin] in
@@ -2194,7 +2216,7 @@ static int wgrad_reduce_runs(int split, int64_t total) {
 // right of every Q row stand for the frame's edges, and taps above/below the frame are skipped.  Wave
 // w owns the sixteen rows 16 (w % NRB) of the gradient and an equal share of the taps.  Each workgroup
 // writes its partial gradient as one slab for wgrad_reduce_kernel.
-template <int C1, int C2, int WAVES_PER_EU, bool XP, bool XQ, bool BF, int ST = 0>
+template <int C1, int C2, int WAVES_PER_EU, bool XP, bool XQ, int BF, int ST = 0>      // BF: 0 fp32, 1 bf16, 2 fp32 from bf16 terms
 __global__ void __launch_bounds__(256, WAVES_PER_EU) wgrad_rows_kernel(WgradArgs g) {
   constexpr int NRB = C1 / 16;            // row blocks of the gradient
   constexpr int CPARTS = 4 / NRB;         // the taps are shared between this many waves per row block
@@ -2252,7 +2274,7 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) wgrad_rows_kernel(WgradArgs
     for (int e = 0; e < 4; ++e) v[e] = fmaxf(z[e], zs[e]);
     return v;
   };
-  static_assert(BF || ST == 0, "bf16 storage goes with bf16 MFMA operands");
+  static_assert(BF == 1 || ST == 0, "bf16 storage goes with bf16 MFMA operands");
   constexpr bool pbf = (ST & DVAE_ST_X) != 0, qbf = (ST & DVAE_ST_Y) != 0;
   auto fetch_p = [&](int64_t row, f32x4 (&raw)[NLP]) {
     const bool rok = row >= 0 && row < rows;
@@ -2329,7 +2351,31 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) wgrad_rows_kernel(WgradArgs
         if (hin < 0 || hin >= 2 * Hs) continue;    // the tap row is above or below the frame
         const float* qrow = qring + ((2 * r - 1 + dh) & 7) * qslot;
         // Q pixel of (b, dw) is column 2b-1+dw, stored at index 2b+dw
-        if constexpr (BF) {
+        if constexpr (BF == 2) {
+          const SplitQuad af = split_quad(av[0], av[1], av[2], av[3]);
+          // two taps at a time: four (two) independent accumulators per term, few split operands alive
+#pragma unroll
+          for (int dw0 = 0; dw0 < 4; dw0 += 2) {
+            SplitQuad bs[2][NCB];
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+              for (int cb = 0; cb < NCB; ++cb) {
+                const float* qa = qrow + (2 * b0 + dw0 + d) * PSQ + 16 * cb + i16;
+                bs[d][cb] = split_quad(qa[0], qa[2 * PSQ], qa[4 * PSQ], qa[6 * PSQ]);
+              }
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+              for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+                  acc[dl][dw0 + d][cb] =
+                      RowOps<true>::mma(af.t[SPLIT_TA[t]], bs[d][cb].t[SPLIT_TB[t]], acc[dl][dw0 + d][cb]);
+          }
+          continue;
+        }
+        if constexpr (BF == 1) {
           // the lane's four pixels are the four k of one bf16 MFMA operand
           const s16x4 af = bf_quad(av[0], av[1], av[2], av[3]);
 #pragma unroll
@@ -2388,9 +2434,9 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) wgrad_rows_kernel(WgradArgs
 // layer's raw output; a row becomes scale*dz + A*y + B on its way into LDS).  Every Q row is met by
 // exactly two filter rows; the workgroups of filter rows 1 and 2 between them meet each row once and
 // write the finished rows to dx_out for the data-gradient kernel.
-template <bool XP, bool XQ, bool BNQ, bool BF, int ST = 0>
+template <bool XP, bool XQ, bool BNQ, int BF, int ST = 0>      // BF: 0 fp32, 1 bf16, 2 fp32 from bf16 terms
 __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
-  static_assert(BF || ST == 0, "bf16 storage goes with bf16 MFMA operands");
+  static_assert(BF == 1 || ST == 0, "bf16 storage goes with bf16 MFMA operands");
   static_assert(ST == 0 || (BNQ && ST == (DVAE_ST_Y | DVAE_ST_INY)), "bf16 storage: Q and q_y of the BatchNorm-backward form");
   constexpr bool qbf = (ST & DVAE_ST_Y) != 0, qybf = (ST & DVAE_ST_INY) != 0;
   constexpr int C1 = 128, C2 = 64, Ws = 8, WQ = 16, NCB = C2 / 16;
@@ -2506,7 +2552,34 @@ __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
   __syncthreads();
   for (int64_t p = p0; p < p1; ++p) {
     fetch(p + 1, raw);
-    if constexpr (BF) {
+    if constexpr (BF == 2) {
+      const int h = kq >> 1, b0 = (4 * kq) & 7;
+      const float* prow = pbuf[p & 1][h];
+      const float* qrow = qbuf[p & 1][h];
+      SplitQuad af[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const float* pa = prow + b0 * PSP + 16 * (2 * wave + r) + i16;
+        af[r] = split_quad(pa[0], pa[PSP], pa[2 * PSP], pa[3 * PSP]);
+      }
+#pragma unroll
+      for (int dw = 0; dw < 4; ++dw) {
+        SplitQuad bs[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const float* qa = qrow + (2 * b0 + dw) * PSQ + 16 * cb + i16;
+          bs[cb] = split_quad(qa[0], qa[2 * PSQ], qa[4 * PSQ], qa[6 * PSQ]);
+        }
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+              acc[r][dw][cb] = RowOps<true>::mma(af[r].t[SPLIT_TA[t]], bs[cb].t[SPLIT_TB[t]], acc[r][dw][cb]);
+      }
+    }
+    if constexpr (BF == 1) {
       // the lane's four pixels 4kq..4kq+3 (one row of the pair: 4kq+3 < 8 or 4kq >= 8) are the four k of one
       // bf16 MFMA operand
       const int h = kq >> 1, b0 = (4 * kq) & 7;
@@ -2529,7 +2602,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
         }
     }
 #pragma unroll
-    for (int e = 0; e < (BF ? 0 : 4); ++e) {
+    for (int e = 0; e < (BF != 0 ? 0 : 4); ++e) {
       const int pos = 4 * kq + e, h = pos >> 3, b = pos & 7;     // this lane's pixel of the K group
       const float* prow = pbuf[p & 1][h];
       const float* qrow = qbuf[p & 1][h];
@@ -2571,7 +2644,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_rows8_kernel(WgradArgs g) {
 // into LDS pixel by pixel (zeros where the tap leaves the frame).  Wave w owns gradient rows
 // 64w .. 64w+63.  The sixteen workgroups of a split are numbered so that they land on one XCD close
 // together in time and share the frame through that XCD's L2.
-template <bool XP, bool XQ, bool BF>
+template <bool XP, bool XQ, int BF>      // BF: 0 fp32, 1 bf16, 2 fp32 from bf16 terms
 __global__ void __launch_bounds__(256, 2) wgrad_img4_kernel(WgradArgs g) {
   constexpr int C1 = 256, C2 = 128, NCB = C2 / 16;
   constexpr int PSP = C1 + 4, PSQ = C2 + 4, P4 = C1 / 4, Q4 = C2 / 4;
@@ -2658,7 +2731,24 @@ __global__ void __launch_bounds__(256, 2) wgrad_img4_kernel(WgradArgs g) {
     fetch(n + 1, raw);
     const float* pp = pbuf[n & 1];
     const float* qq = qbuf[n & 1];
-    if constexpr (BF) {
+    if constexpr (BF == 2) {
+      SplitQuad af[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* pa = pp + 4 * kq * PSP + 16 * (4 * wave + r) + i16;
+        af[r] = split_quad(pa[0], pa[PSP], pa[2 * PSP], pa[3 * PSP]);
+      }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const float* qa = qq + 4 * kq * PSQ + 16 * cb + i16;
+        const SplitQuad bs = split_quad(qa[0], qa[PSQ], qa[2 * PSQ], qa[3 * PSQ]);
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r][cb] = RowOps<true>::mma(af[r].t[SPLIT_TA[t]], bs.t[SPLIT_TB[t]], acc[r][cb]);
+      }
+    }
+    if constexpr (BF == 1) {
       // the lane's four pixels 4kq..4kq+3 are the four k of one bf16 MFMA operand
       s16x4 af[4];
 #pragma unroll
@@ -2675,7 +2765,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_img4_kernel(WgradArgs g) {
       }
     }
 #pragma unroll
-    for (int e = 0; e < (BF ? 0 : 4); ++e) {
+    for (int e = 0; e < (BF != 0 ? 0 : 4); ++e) {
       const int pos = 4 * kq + e;                 // this lane's pixel of the K group
       float av[4], bv[NCB];
 #pragma unroll
@@ -2799,6 +2889,16 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
   g.ktiles_per_split = p.ktiles_per_split;
   hipStream_t s = ST(stream);
   const bool wbf = dvae_mfma_precision() == DVAE_PRECISION_BF16;
+  // 'fp32_split' in the three row kernels whose operands meet in LDS: correct, and slower than their fp32 MFMA form
+  // on this part (0.87 / 0.83 / 0.71 ms against 0.69 / 0.77 / 0.73 at batch 256): the lanes hold four k per
+  // operand, which is v_mfma_f32_16x16x16_bf16 -- half the bf16 rate of gfx950's 16x16x32 form -- so six of them
+  // save a quarter of the matrix time of four fp32 MFMAs, and the two dozen vector instructions that split a quad
+  // cost more than that.  Only on request (DVAE_SPLIT_ROW_WGRAD=1); by default these kernels stay on the fp32 MFMA
+  // in that mode.
+  const bool wsp = dvae_mfma_precision() == DVAE_PRECISION_F32_SPLIT && [] {
+    const char* v = getenv("DVAE_SPLIT_ROW_WGRAD");
+    return v != nullptr && v[0] == '1';
+  }();
   DVAE_REQUIRE(storage == 0 || (wbf && ((p.bm == -1 && (storage == DVAE_ST_Y || storage == (DVAE_ST_X | DVAE_ST_Y))) ||
                                         (p.bm == -2 && storage == (DVAE_ST_Y | DVAE_ST_INY) && g.q_y != nullptr) ||
                                         (p.bm == 0 && storage == DVAE_ST_X && C1 == 32 && g.p_y == nullptr) ||
@@ -2808,8 +2908,9 @@ static int conv4s2_wgrad_impl(const float* P, const float* p_scale, const float*
   // a row-ring kernel in the variant of the current MFMA precision
 #define WG_BF(NAME, LDS, ...)                                                                           \
   {                                                                                                     \
-    if (wbf) DVAE_LAUNCH((NAME<__VA_ARGS__, true>), grid, dim3(256), LDS, s, g);                        \
-    else DVAE_LAUNCH((NAME<__VA_ARGS__, false>), grid, dim3(256), LDS, s, g);                           \
+    if (wbf) DVAE_LAUNCH((NAME<__VA_ARGS__, 1>), grid, dim3(256), LDS, s, g);                           \
+    else if (wsp) DVAE_LAUNCH((NAME<__VA_ARGS__, 2>), grid, dim3(256), LDS, s, g);                      \
+    else DVAE_LAUNCH((NAME<__VA_ARGS__, 0>), grid, dim3(256), LDS, s, g);                               \
   }
   DVAE_REQUIRE(q_y == nullptr || (p.bm == -2 && q_scale && q_shift && q_a && q_b && dx_out && aligned16(q_y) &&
                                   aligned16(q_a) && aligned16(q_b) && aligned16(dx_out)),

@@ -341,9 +341,15 @@ def test_conv4s2_wgrad(ops, N, Hs, C1, C2):
     assert rel_err(got, dw) < 5e-6
 
 
-@pytest.mark.parametrize('N,Hs,C1,C2', [(3, 8, 64, 32), (3, 2, 256, 128), (9, 8, 256, 256), (40, 16, 16, 8)])
-def test_conv4s2_wgrad_in_split_precision_is_fp32_accurate(ops, N, Hs, C1, C2):
-    """the tiled weight-gradient kernel in 'fp32_split' mode keeps the fp32 bar"""
+@pytest.mark.parametrize('N,Hs,C1,C2', [(3, 8, 64, 32), (3, 2, 256, 128), (9, 8, 256, 256), (40, 16, 16, 8),
+                                        # the row kernels whose operands meet in LDS: 64 x 32 and 32 x 16 (16 and 32
+                                        # pixels wide), 128 x 64 on 8-wide P, 256 x 128 on 4 x 4 P
+                                        (3, 16, 64, 32), (70, 32, 64, 32), (2, 32, 32, 16), (70, 16, 32, 16),
+                                        (3, 8, 128, 64), (40, 8, 128, 64), (40, 4, 256, 128), (67, 4, 256, 128)])
+def test_conv4s2_wgrad_in_split_precision_is_fp32_accurate(ops, N, Hs, C1, C2, monkeypatch):
+    """the weight-gradient kernels in 'fp32_split' mode keep the fp32 bar (the row kernels take that mode on
+    request only: they are slower in it)"""
+    monkeypatch.setenv('DVAE_SPLIT_ROW_WGRAD', '1')
     x = rnd(N, C2, 2 * Hs, 2 * Hs, seed=35)
     dy = rnd(N, C1, Hs, Hs, seed=36)
     w = torch.zeros(C1, C2, 4, 4, dtype=torch.float64, requires_grad=True)
@@ -354,6 +360,27 @@ def test_conv4s2_wgrad_in_split_precision_is_fp32_accurate(ops, N, Hs, C1, C2):
     finally:
         ops.set_precision('fp32')
     assert rel_err(got, dw) < 5e-6
+
+
+@pytest.mark.parametrize('N,H,Cin,Cout', [(3, 16, 64, 32), (2, 16, 32, 16), (5, 8, 128, 64), (40, 4, 256, 128)])
+def test_wgrad_for_transposed_conv_in_split_precision(ops, N, H, Cin, Cout, monkeypatch):
+    """the row kernels with a load transform on P, operands spread over 2^-12 .. 2^12, in 'fp32_split' mode"""
+    monkeypatch.setenv('DVAE_SPLIT_ROW_WGRAD', '1')
+    x = rnd(N, Cin, H, H, seed=35) * torch.exp2(torch.randint(-12, 13, (N, Cin, 1, 1), generator=torch.Generator().manual_seed(1)).double())
+    sc, sh = 1 + 0.3 * rnd(Cin, seed=36), 0.2 * rnd(Cin, seed=37)
+    xin = O.leaky_relu(x * sc[None, :, None, None] + sh[None, :, None, None])
+    w = torch.zeros(Cin, Cout, 4, 4, dtype=torch.float64, requires_grad=True)
+    y = F.conv_transpose2d(xin, w, None, stride=2, padding=1)
+    dy = rnd(*y.shape, seed=38)
+    (dw,) = torch.autograd.grad(y, w, dy)
+    ops.set_precision('fp32_split')
+    try:
+        got = ops.conv4s2_wgrad(dev(nhwc(x)), dev(sc), dev(sh), ops.ACT_LRELU, dev(nhwc(dy)), None, None, ops.ACT_NONE)
+    finally:
+        ops.set_precision('fp32')
+    plain = ops.conv4s2_wgrad(dev(nhwc(x)), dev(sc), dev(sh), ops.ACT_LRELU, dev(nhwc(dy)), None, None, ops.ACT_NONE)
+    assert rel_err(got, dw) < 5e-6
+    assert rel_err(got, dw) < 2 * rel_err(plain, dw) + 1e-7          # no worse than the fp32 MFMA on the same operands
 
 
 @pytest.mark.parametrize('N,H,Cin,Cout', [(3, 8, 16, 8), (3, 16, 64, 32), (2, 16, 32, 16), (5, 8, 128, 64), (40, 4, 256, 128)])
