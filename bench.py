@@ -434,6 +434,7 @@ def main():
     ring = [synthetic_clips(B, T, size, 1000 * rank + i).to(dev) for i in range(4)]
     beta = 4.0
     graph_fallback = []          # why the captured data-parallel step was given up, if it was
+    dp_runs_mb = []              # sizes of the gradient runs of the captured data-parallel step, one per backward stage
 
     def train_step(i):
         video = ring[i % len(ring)]
@@ -529,6 +530,7 @@ def main():
             print(f'[bench] rank {rank}: captured data-parallel step failed ({why}); eager step instead',
                   file=sys.stderr, flush=True)
         if agreed(gstep is not None):
+            dp_runs_mb[:] = [round((hi - lo) * 4 / 2 ** 20, 2) for lo, hi in gstep.staged.runs]
             return lambda i: gstep(ring[i % len(ring)])
         del gstep
         torch.cuda.synchronize()
@@ -613,7 +615,7 @@ def main():
         'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': dtype_label, 'data': 'synthetic',
         'config': {'workload': f"{cfg['name']} ({args.config}) {args.mode} step, beta=4, {T}x{size}x{size} clips, "
-                               f"batch {B}/GPU, {prec_label}, {('batches from pinned host memory (' + args.host_batches + '), ') if args.host_batches else ''}{('hipGraph replay' + (' (one graph per backward stage -- decoder side, encoders above their convolution stacks, convolution stacks -- the gradients of each stage all-reduced beside the next stage, update graph)' if use_dp else '')) if use_graph else 'eager launches'}",
+                               f"batch {B}/GPU, {prec_label}, {('batches from pinned host memory (' + args.host_batches + '), ') if args.host_batches else ''}{('hipGraph replay' + (' (one graph per backward stage -- decoder side, encoders down to the convolution stack of the per-frame encoder, that stack -- the gradients of each stage all-reduced beside the next stage, update graph)' if use_dp else '')) if use_graph else 'eager launches'}",
                    'global_batch': B * world, 'params': n_params,
                    'parallelism': f'dp{world}'},
     }
@@ -624,8 +626,11 @@ def main():
         result['rccl_world_size'] = dist.get_world_size()
         if graph_fallback:
             result['graph_fallback'] = graph_fallback[0][:300]
-        result['config']['collective'] = ('three all-reduces (AVG) per step over RCCL on a side stream: decoder-side gradients (16 MB) and the encoders\' Linear / LSTM gradients (33 MB) travel beside the backward stages that follow them; only the convolution filters (3 MB) are reduced after backward has ended'
-                                          if use_graph else 'bucketed all-reduces (AVG) over RCCL, overlapped with backward')
+        result['config']['collective'] = (
+            f'{len(dp_runs_mb)} all-reduces (AVG) per step over RCCL on a side stream, one per backward stage '
+            f'({" / ".join(str(x) for x in dp_runs_mb)} MiB): each travels beside the stage that follows it, only the '
+            f'last one is reduced after backward has ended'
+            if use_graph else 'bucketed all-reduces (AVG) over RCCL, overlapped with backward')
     gf = gflop_per_clip(cfg)
     whole = None
     if gf is not None:

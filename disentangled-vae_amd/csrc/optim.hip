@@ -81,6 +81,25 @@ mt_scale_kernel(MTTable t, const float* __restrict__ coef) {
   for (int64_t i = base + threadIdx.x; i < end; i += 256) g[i] *= c;
 }
 
+// dst tensor i <- src tensor i (p = destinations, g = sources): 16-byte pieces where both ends allow it
+__global__ void __launch_bounds__(256)
+mt_copy_kernel(MTTable t) {
+  const int ti = mt_find(t, blockIdx.x);
+  const int64_t base = (int64_t)(blockIdx.x - t.chunk_start[ti]) * MT_CHUNK;
+  const int64_t n = t.numel[ti];
+  float* __restrict__ d = (float*)t.p[ti];
+  const float* __restrict__ s = (const float*)t.g[ti];
+  const int64_t end = base + MT_CHUNK < n ? base + MT_CHUNK : n;
+  if ((((uintptr_t)d | (uintptr_t)s) & 15) == 0) {
+    const int64_t end4 = base + ((end - base) & ~(int64_t)3);
+    for (int64_t i = base + 4 * threadIdx.x; i < end4; i += 1024)
+      *reinterpret_cast<float4*>(d + i) = *reinterpret_cast<const float4*>(s + i);
+    for (int64_t i = end4 + threadIdx.x; i < end; i += 256) d[i] = s[i];
+  } else {
+    for (int64_t i = base + threadIdx.x; i < end; i += 256) d[i] = s[i];
+  }
+}
+
 // `dyn` (optional, device): {step count, learning rate, 1 - beta1^step, sqrt(1 - beta2^step)}, kept up
 // to date by adam_advance_kernel.  When given, the step size and the bias corrections are read from it,
 // so a captured graph replays correctly as the step count and the learning rate move; the host-side
@@ -187,6 +206,23 @@ extern "C" int dvae_scale_tensors_f32(int64_t n, float* const* tensors, const in
     for (int i = 0; i < t.n; ++i) t.g[i] = (void*)tensors[first + i];
     DVAE_LAUNCH(mt_scale_kernel, dim3(blocks), dim3(256), 0, ST(stream), t, coef);
     DVAE_LAUNCH_CHECK("scale_tensors");
+  }
+  return 0;
+}
+
+extern "C" int dvae_copy_tensors_f32(int64_t n, float* const* dst, const float* const* src, const int64_t* numel,
+                                     dvae_stream_t stream) {
+  DVAE_REQUIRE(n > 0, "copy_tensors: no tensors");
+  for (int64_t first = 0; first < n; first += MT_MAX) {
+    MTTable t;
+    const int blocks = fill_table(t, first, n, numel);
+    for (int i = 0; i < t.n; ++i) {
+      t.p[i] = (void*)dst[first + i];
+      t.g[i] = (void*)src[first + i];
+    }
+    { double el = 0; for (int i = 0; i < t.n; ++i) el += (double)t.numel[i]; DVAE_WORK(8.0 * el, DVAE_UNIT_BYTE); }
+    DVAE_LAUNCH(mt_copy_kernel, dim3(blocks), dim3(256), 0, ST(stream), t);
+    DVAE_LAUNCH_CHECK("copy_tensors");
   }
   return 0;
 }

@@ -119,6 +119,7 @@ SIGNATURES = {
     'dvae_grad_norm_ws_floats': (L, [L, POINTER(c_int64)]),
     'dvae_grad_norm_f32': (I, [L, POINTER(c_void_p), POINTER(c_int64), F, P, P, P]),
     'dvae_scale_tensors_f32': (I, [L, POINTER(c_void_p), POINTER(c_int64), P, P]),
+    'dvae_copy_tensors_f32': (I, [L, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), P]),
     'dvae_adam_step_f32': (I, [L, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                POINTER(c_int64), F, F, F, F, F, F, F, P, P, P]),
     'dvae_trace_begin': (I, [L]),

@@ -308,14 +308,16 @@ class EncoderFC(torch.autograd.Function):
         return du, d_fc_w, d_fc_b
 
 
-def encoder_cnn(x: Tensor, training: bool, bns: List[BNState], fc_w: Tensor, fc_b: Tensor, *wgb: Tensor) -> Tensor:
-    """CNNEncoder / LightCNNEncoder of the reference (models/encoders.py:11-97) as two autograd nodes, with the
-    second cut of a staged data-parallel step between them: the Linear layer's weight gradient (the largest
+def encoder_cnn(x: Tensor, training: bool, bns: List[BNState], fc_w: Tensor, fc_b: Tensor, *wgb: Tensor,
+                stage_cut: bool = True) -> Tensor:
+    """CNNEncoder / LightCNNEncoder of the reference (models/encoders.py:11-97) as two autograd nodes, with (stage_cut)
+    the second cut of a staged data-parallel step between them: the Linear layer's weight gradient (the largest
     gradient tensor of the encoders) is then complete, and can travel, before the convolution stack's backward
     runs."""
     from .parallel import stage_boundary
     u = EncoderConvs.apply(x, training, bns, *wgb)
-    (u,) = stage_boundary(u, level=2)
+    if stage_cut:
+        (u,) = stage_boundary(u, level=2)
     return EncoderFC.apply(u, fc_w, fc_b)
 
 

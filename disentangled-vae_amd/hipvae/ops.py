@@ -1025,6 +1025,16 @@ def scale_tensors(tensors: List[Tensor], coef: Tensor, table: Optional[TensorTab
     check(lib.dvae_scale_tensors_f32(n, g, numel, _p(coef), _stream()), 'scale_tensors')
 
 
+def copy_tensors(dsts: List[Tensor], srcs: List[Tensor], table: Optional[TensorTable] = None):
+    """dsts[i] <- srcs[i] for a list of equally sized fp32 tensors, one launch per 48 of them."""
+    table = table or TensorTable()
+    for d, s_ in zip(dsts, srcs):
+        if d.numel() != s_.numel():
+            raise RuntimeError("copy_tensors: sizes differ")
+    n, (d, s_), numel = table.get([dsts, srcs])
+    check(lib.dvae_copy_tensors_f32(n, d, s_, numel, _stream()), 'copy_tensors')
+
+
 def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
               grad_coef: Optional[Tensor], table: Optional[TensorTable] = None, dyn: Optional[Tensor] = None):
     """dyn: device tensor {step count, learning rate, 1-beta1^t, sqrt(1-beta2^t)} maintained by

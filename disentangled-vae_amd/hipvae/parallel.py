@@ -210,12 +210,13 @@ class StagedGrads:
         self._levels = []
         self._laid_out = False
         self._seen = {}               # first step only: id(parameter) -> (gradient tensor, its version) when placed
+        self._copy_tables = {}        # run -> host-side pointer arrays of its multi-tensor copy
 
     # ---- layout -------------------------------------------------------------------------------
     def _place(self, run: int, last: bool):
         """first step: the parameters whose gradient appeared in this stage form the next run of the buffer"""
         if self.flat is None:
-            n = sum(p.numel() for p in self.params)
+            n = sum((p.numel() + 3) // 4 * 4 for p in self.params)
             self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.device)
         for p in self.params:                        # a gradient that grew after its run was closed
             seen = self._seen.get(id(p))
@@ -230,7 +231,7 @@ class StagedGrads:
             self._run_of[id(p)] = run
             self.order.append(p)
             self.views[id(p)] = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+            off += (p.numel() + 3) // 4 * 4          # every view starts on a 16-byte boundary (the gaps stay zero)
             if p.grad is not None:
                 self._seen[id(p)] = (p.grad, p.grad._version)
         self.runs.append((lo, off))
@@ -245,7 +246,11 @@ class StagedGrads:
         for p in ps:
             if p.grad is None:
                 self.views[id(p)].zero_()
-        if have:
+        if have and self.on_gpu and all(p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in have):
+            from . import ops              # one launch of the library's multi-tensor copy (pointer table in its arguments)
+            ops.copy_tensors([self.views[id(p)] for p in have], [p.grad for p in have],
+                             self._copy_tables.setdefault(run, ops.TensorTable()))
+        elif have:
             torch._foreach_copy_([self.views[id(p)] for p in have], [p.grad for p in have])
 
     def _after_stage(self, run: int):

@@ -47,6 +47,10 @@ def _frames_nhwc(x: torch.Tensor) -> torch.Tensor:
 
 class _ConvEncoderBase(nn.Module):
     final_hw = 4
+    # whether a staged data-parallel step may cut this encoder's backward between its Linear layer and its
+    # convolution stack (hipvae.functional.encoder_cnn).  An encoder that sees one frame per clip switches it off:
+    # its whole backward is a chain of small kernels that runs best beside another branch's recurrence.
+    stage_cut = True
 
     def __init__(self, in_channels, channels, kernel_size, stride, padding, output_dim, use_batch_norm):
         super().__init__()
@@ -61,7 +65,7 @@ class _ConvEncoderBase(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         ws, gs, bs, handles = _stack_tensors(self.conv)
         return HF.encoder_cnn(_frames_nhwc(x), self.training, handles, self.fc[0].weight, self.fc[0].bias,
-                                   *ws, *gs, *bs)
+                              *ws, *gs, *bs, stage_cut=self.stage_cut)
 
 
 class CNNEncoder(_ConvEncoderBase):
@@ -170,6 +174,7 @@ class ContentEncoder(nn.Module):
         self.aggregation = aggregation
         self.latent_dim = latent_dim
         self.cnn_encoder = CNNEncoder(in_channels=in_channels, channels=channels, output_dim=feature_dim)
+        self.cnn_encoder.stage_cut = False         # one frame per clip: see _ConvEncoderBase.stage_cut
         self.vae_head = VAEEncoder(input_dim=feature_dim, latent_dim=latent_dim)
 
     def forward(self, video: torch.Tensor, return_distribution: bool = True, _mean: Optional[torch.Tensor] = None):

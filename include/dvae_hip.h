@@ -550,6 +550,11 @@ int dvae_grad_norm_f32(int64_t n, const float* const* grads, const int64_t* nume
 /* Scales every gradient in place by *coef (device scalar). */
 int dvae_scale_tensors_f32(int64_t n, float* const* tensors, const int64_t* numel, const float* coef,
                            dvae_stream_t stream);
+/* dst[i] <- src[i] for n tensors of numel[i] floats in one launch per 48 tensors (the gradients of one backward
+ * stage into their run of a data-parallel step's flat buffer).  No counterpart in the reference (it has no
+ * data parallelism). */
+int dvae_copy_tensors_f32(int64_t n, float* const* dst, const float* const* src, const int64_t* numel,
+                          dvae_stream_t stream);
 /* One Adam step on n tensors; gradients are multiplied by *grad_coef (device scalar, NULL = 1) as
  * they are read.  bias_correction1 = 1-beta1^t, bias_correction2 = 1-beta2^t computed by the caller,
  * unless dyn is given: four device floats {step count t, learning rate, 1-beta1^t, sqrt(1-beta2^t)};

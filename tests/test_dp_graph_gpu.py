@@ -103,13 +103,15 @@ def _worker(rank, world, port, out_dir):
                     t.data.copy_(_via_host(t.data, lambda h: dist.broadcast(h, src=0)))
             step = HostReducedStep(m, opt, loss_of, batches[0], gradient_clip=1.0, broadcast_parameters=False)
             trace('captured')
-            # three runs, three backward graphs: decoder | encoders above their convolution stacks | the stacks
+            # three runs, three backward graphs: decoder | encoders above the motion encoder's convolution stack (the
+            # content encoder, one frame per clip, is not cut: its whole backward runs beside the recurrence) | that stack
             st = step.staged
             assert st.nstages == 3 and len(st.runs) == 3 and len(step.stage_graphs) == 2
             assert 0 < st.runs[0][1] == st.runs[1][0] < st.runs[1][1] == st.runs[2][0] < st.runs[2][1] == st.flat.numel()
             run_of = {n: st._run_of[id(p)] for n, p in m.named_parameters()}
             assert all((r == 0) == n.startswith('decoder.') for n, r in run_of.items())
-            assert all((r == 2) == ('.cnn_encoder.conv.' in n) for n, r in run_of.items()), run_of
+            assert all((r == 2) == ('motion_encoder.cnn_encoder.conv.' in n) for n, r in run_of.items()), run_of
+            assert run_of['content_encoder.cnn_encoder.conv.0.weight'] == 1
             assert run_of['motion_encoder.cnn_encoder.fc.0.weight'] == 1
             for v in batches:
                 step(v)

@@ -147,9 +147,10 @@ def _staged_worker(rank, world, port, out_dir):
         with torch.no_grad():
             for p in net.parameters():
                 p -= 0.01 * p.grad
-    n_dec = sum(p.numel() for p in net.dec.parameters())
-    n_enc = sum(p.numel() for p in list(net.enc.parameters()) + list(net.enc2.parameters()))
-    n_all = sum(p.numel() for p in net.parameters())
+    pad = lambda ps: sum((p.numel() + 3) // 4 * 4 for p in ps)       # noqa: E731  (views start on 16-byte boundaries)
+    n_dec = pad(net.dec.parameters())
+    n_enc = pad(list(net.enc.parameters()) + list(net.enc2.parameters()))
+    n_all = pad(net.parameters())
     # the parameter that never receives a gradient travels (as zeros) with the last run
     assert events[:6] == [('stage1',), ('reduce', n_dec), ('stage2',), ('reduce', n_enc), ('stage3',),
                           ('reduce', n_all - n_dec - n_enc)], events[:6]
