@@ -347,6 +347,85 @@ def cpu_baseline(kind, cfg, steps=10, warmup=3, batch=32):
             'inference': {'value': round(batch / imed, 2), 'unit': 'clips/s'}}
 
 
+def other_sections(steps, warmup, batch, config_name='disentangled_simple.json'):
+    """The measurements beside the headline that need models of their own (`bench.py --section others`): the three
+    batch-32 configurations, LSTMVAE at `batch`, the 128 x 128 x 40 configuration at batch 32 (hipGraph replay on a ring
+    of four synthetic batches, like the headline) and one epoch of the Trainer at batch 32 and `batch`."""
+    import gc
+    import torch
+    dev = torch.device('cuda', torch.cuda.current_device())
+    import models
+    from hipvae import losses as L
+    from hipvae.graph import GraphedTrainStep
+    from hipvae.optim import FusedAdam
+    beta = 4.0
+
+    def release(what):
+        # graphs, models and rings of a finished section go back to the device before the next one captures
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        print(f'[bench] after {what}: {torch.cuda.memory_reserved() / 2 ** 30:.1f} GiB reserved', file=sys.stderr, flush=True)
+
+    def timed(step_fn):
+        for i in range(warmup):
+            step_fn(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step_fn(i)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def graphed_rate(cfg_name, b):
+        c2 = load_config(cfg_name)
+        k2, t2 = c2['model']['model_type'], c2['training']
+        T2, S2 = c2['data']['sequence_length'], c2['data']['frame_size']
+        torch.manual_seed(0)
+        m2 = models.get_model(k2, **model_kwargs(c2)).to(dev).train()
+        o2 = FusedAdam(m2.parameters(), lr=t2['learning_rate'], betas=(t2['beta1'], t2['beta2']),
+                       weight_decay=t2['weight_decay'])
+        r2 = [synthetic_clips(b, T2, S2, 7000 + i).to(dev) for i in range(4)]
+        g2 = GraphedTrainStep(m2, o2, lambda mm, v: loss_call(k2, L, mm(v), v, t2, beta), r2[0],
+                              gradient_clip=t2['gradient_clip'])
+        ms2 = timed(lambda i: g2(r2[i % 4])) / steps * 1e3
+        gf2 = gflop_per_clip(c2)[1]
+        del g2, m2, o2, r2
+        release(f'{cfg_name} at batch {b}')
+        return {'batch': b, 'clip': f'{T2}x{S2}x{S2}', 'ms_per_step': round(ms2, 3),
+                'value': round(b / ms2 * 1e3, 1), 'unit': 'clips/s', 'gflop_per_clip': gf2,
+                'whole_step_frac': round(gf2 * b / ms2 / PEAK_FP32_MFMA_TFLOPS, 4)}
+
+    out = {'batch32_configs': {n: graphed_rate(n, 32) for n in ('disentangled_simple.json', 'lstm_simple.json',
+                                                                'small_baseline.json')}}
+    out['other_configs'] = {'lstm_simple.json': graphed_rate('lstm_simple.json', batch),
+                            'disentangled_128x128x40.json': graphed_rate('disentangled_128x128x40.json', 32)}
+    try:
+        out['trainer_epoch'] = {f'batch{b}': trainer_epoch(config_name, b) for b in sorted({32, batch})}
+    except Exception as e:                                          # noqa: BLE001
+        out['trainer_epoch'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+    return out
+
+
+def other_sections_in_child(args, batch):
+    """other_sections() in a process of its own; its result dictionary, or a one-entry dictionary saying what
+    happened to the child."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--section', 'others', '--steps', str(args.steps),
+           '--warmup', str(args.warmup), '--batch', str(batch)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=1500, text=True)      # (stderr passes through)
+    except subprocess.TimeoutExpired:
+        return {'other_sections_error': 'the child process did not finish within 1500 s'}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    if r.returncode != 0 or not lines:
+        return {'other_sections_error': f'the child process ended with status {r.returncode}'}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {'other_sections_error': f'unreadable result of the child process: {e}'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -368,6 +447,8 @@ def main():
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group and use the data-parallel step even with one rank '
                          '(exercises the multi-GPU code path on a single GPU)')
+    ap.add_argument('--section', default='', choices=['', 'others'],
+                    help="'others': only the measurements beside the headline (what the default run asks of a child process)")
     ap.add_argument('--trainer', action='store_true',
                     help='measure Trainer.train_epoch() + validate() (what the CLI runs: 10,000 / 1,000 generated clips) '
                          'at batch 32 and at --batch instead of the device-resident ring, and print that as the line')
@@ -405,6 +486,11 @@ def main():
 
     ops.set_precision(args.precision)
     cfg = load_config(args.config)
+    if args.section == 'others':
+        if world != 1:
+            raise SystemExit("--section others is a single-GPU measurement")
+        print(json.dumps(other_sections(args.steps, args.warmup, args.batch, args.config)), flush=True)
+        return
     if args.trainer:
         if world != 1:
             raise SystemExit("--trainer measures the single-GPU command line")
@@ -697,41 +783,18 @@ def main():
                             'not the headline value'}
             ops.set_precision('fp32')
         if args.config == 'disentangled_simple.json' and args.precision == 'fp32':
-            # BASELINE configurations 2 and 3 (batch 32 on one GPU, fp32) and the small baseline beside them; then
-            # LSTMVAE at the headline's batch and the 128 x 128 x 40 configuration (BASELINE configuration 5) at 32
-            from hipvae.graph import GraphedTrainStep
-
-            def graphed_rate(cfg_name, batch):
-                c2 = load_config(cfg_name)
-                k2, t2 = c2['model']['model_type'], c2['training']
-                T2, S2 = c2['data']['sequence_length'], c2['data']['frame_size']
-                torch.manual_seed(0)
-                m2 = models.get_model(k2, **model_kwargs(c2)).to(dev).train()
-                o2 = FusedAdam(m2.parameters(), lr=t2['learning_rate'], betas=(t2['beta1'], t2['beta2']),
-                               weight_decay=t2['weight_decay'])
-                r2 = [synthetic_clips(batch, T2, S2, 7000 + i).to(dev) for i in range(4)]
-                g2 = GraphedTrainStep(m2, o2, lambda mm, v: loss_call(k2, L, mm(v), v, t2, beta), r2[0],
-                                      gradient_clip=t2['gradient_clip'])
-                el, _ = measure(lambda i: g2(r2[i % 4]), args.steps, args.warmup)
-                ms2 = el / args.steps * 1e3
-                gf2 = gflop_per_clip(c2)[1]
-                return {'batch': batch, 'clip': f'{T2}x{S2}x{S2}', 'ms_per_step': round(ms2, 3),
-                        'value': round(batch / ms2 * 1e3, 1), 'unit': 'clips/s', 'gflop_per_clip': gf2,
-                        'whole_step_frac': round(gf2 * batch / ms2 / PEAK_FP32_MFMA_TFLOPS, 4)}
-            others = {n: graphed_rate(n, 32) for n in ('disentangled_simple.json', 'lstm_simple.json',
-                                                       'small_baseline.json')}
-            result['batch32_configs'] = others
-            result['other_configs'] = {'lstm_simple.json': graphed_rate('lstm_simple.json', B),
-                                       'disentangled_128x128x40.json': graphed_rate('disentangled_128x128x40.json', 32)}
-            # the rate of the command-line path beside the ring numbers above: one epoch of the Trainer
-            try:
-                result['trainer_epoch'] = {f'batch{b}': trainer_epoch(args.config, b) for b in sorted({32, B})}
-                ring = {B: result['value'], 32: others['disentangled_simple.json']['value']}
+            # BASELINE configurations 2 and 3 (batch 32 on one GPU, fp32) and the small baseline beside them, LSTMVAE
+            # at the headline's batch, the 128 x 128 x 40 configuration (BASELINE configuration 5) at 32, and the
+            # Trainer's own epoch loop: measured by a child process, so that nothing that goes wrong there (an abort
+            # inside the runtime cannot be caught) takes the result line above with it
+            extra = other_sections_in_child(args, B)
+            result.update(extra)
+            if 'trainer_epoch' in extra and 'error' not in extra['trainer_epoch'] and 'batch32_configs' in extra:
+                ring_rate = {B: result['value'], 32: extra['batch32_configs']['disentangled_simple.json']['value']}
                 for b in sorted({32, B}):
-                    result['trainer_epoch'][f'batch{b}']['vs_ring'] = round(
-                        result['trainer_epoch'][f'batch{b}']['train_clips_per_s'] / ring[b], 4)
-            except Exception as e:                                          # noqa: BLE001
-                result['trainer_epoch'] = {'error': f'{type(e).__name__}: {e}'[:300]}
+                    row = extra['trainer_epoch'].get(f'batch{b}')
+                    if row:
+                        row['vs_ring'] = round(row['train_clips_per_s'] / ring_rate[b], 4)
     if use_dp:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == 'train':

@@ -11,6 +11,7 @@ prepared draws through hipvae.rng.inject_eps, static buffers that receive the ne
 Values baked into the graph: shapes and the other loss weights.
 """
 import contextlib
+import gc
 from typing import Callable, Dict, Optional
 
 import torch
@@ -20,6 +21,23 @@ from . import rng
 
 
 _CAPTURE_STREAMS = {}
+
+
+@contextlib.contextmanager
+def quiet_collector():
+    """Around a capture: Python's cycle collector runs now and not again until the capture has ended.  A graph that
+    an earlier step left behind in a reference cycle (closures over the step object are enough) is destroyed
+    whenever the collector next runs, and destroying a graph is not allowed while a stream of the thread captures:
+    the runtime refuses, the destructor throws, the process aborts.  torch.cuda.graph collects before capturing
+    only when torch.compiler.config.force_cudagraph_gc is set."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def capture_stream(device=None) -> torch.cuda.Stream:
@@ -99,7 +117,8 @@ class GraphedTrainStep:
         # thread-local capture mode: other threads of the process (a DataLoader's pinning thread, a checkpoint
         # writer, a process group's watchdog) may call the runtime while this thread captures
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self._capture_stream, capture_error_mode='thread_local'):
+        with quiet_collector(), torch.cuda.graph(self.graph, stream=self._capture_stream,
+                                                 capture_error_mode='thread_local'):
             self.losses = self._step()
 
     def _before_replay(self, video: torch.Tensor):
@@ -147,7 +166,8 @@ class GraphedForward:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local'), torch.no_grad():
+        with quiet_collector(), torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local'), \
+                torch.no_grad():
             self.out = self.fn(model, self.static_in)
 
     def __call__(self, batch: torch.Tensor):
@@ -242,16 +262,18 @@ class GraphedDataParallelStep(GraphedTrainStep):
         torch.cuda.current_stream().wait_stream(self.staged.comm_stream)
         cs = self._capture_stream
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=cs, capture_error_mode='thread_local'):
+        with quiet_collector(), torch.cuda.graph(self.graph, stream=cs, capture_error_mode='thread_local'):
             self.losses = self._stage1()
         self.stage_graphs = []                     # stages 2.. in order
         for k in range(2, self.staged.nstages + 1):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.graph.pool(), stream=cs, capture_error_mode='thread_local'):
+            with quiet_collector(), torch.cuda.graph(g, pool=self.graph.pool(), stream=cs,
+                                                     capture_error_mode='thread_local'):
                 self.staged.stage(k)
             self.stage_graphs.append(g)
         self.graph_update = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_update, pool=self.graph.pool(), stream=cs, capture_error_mode='thread_local'):
+        with quiet_collector(), torch.cuda.graph(self.graph_update, pool=self.graph.pool(), stream=cs,
+                                                 capture_error_mode='thread_local'):
             # (finish() makes the capturing stream wait for the communication stream: outside capture)
             for p in self.staged.order:
                 p.grad = self.staged.views[id(p)]

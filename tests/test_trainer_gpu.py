@@ -643,3 +643,18 @@ def test_graphed_forward_replays_the_eval_forward():
             want = m(v)
         for k in want:
             assert torch.equal(got[k], want[k]), k
+
+
+def test_a_dead_graph_in_a_reference_cycle_does_not_abort_the_next_capture():
+    """Python's cycle collector may run at any allocation.  If it destroys an old captured step while a new one is
+    being captured the runtime refuses and the process aborts (seen in bench.py: a whole run lost in its last
+    section); every capture of hipvae.graph therefore collects first and keeps the collector quiet until it has
+    ended.  tools/debug/gc_probe.py leaves three dead steps in reference cycles and runs the collector inside the
+    next captured region: 'ok' with the guard, abort (exit status 134) with `--unguarded`.  Run as a child process:
+    the failure mode is an abort, not an exception."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = os.path.join(root, 'tools', 'debug', 'gc_probe.py')
+    r = subprocess.run([sys.executable, probe], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), (r.returncode, r.stderr[-2000:])
