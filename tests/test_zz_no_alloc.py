@@ -71,7 +71,8 @@ def test_no_alloc_entry_point_under_graph_capture():
     out = torch.full((3,), -1.0, device='cuda')
     side = torch.cuda.Stream()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):
+    from hipvae.graph import quiet_collector      # (a dead graph of an earlier test must not be collected in here)
+    with quiet_collector(), torch.cuda.graph(g, stream=side):
         _no_alloc(lib, recon, target, 1.0, out)
     for clips in (a, b):
         recon.copy_(clips[0])
