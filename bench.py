@@ -783,8 +783,8 @@ def main():
                             'not the headline value'}
             ops.set_precision('fp32')
         if args.config == 'disentangled_simple.json' and args.precision == 'fp32':
-            # BASELINE configurations 2 and 3 (batch 32 on one GPU, fp32) and the small baseline beside them, LSTMVAE
-            # at the headline's batch, the 128 x 128 x 40 configuration (BASELINE configuration 5) at 32, and the
+            # the reference's own batch-32 configurations (DisentangledVAE, LSTMVAE, fp32) and the small baseline beside
+            # them, LSTMVAE at the headline's batch, the 128 x 128 x 40 configuration at batch 32, and the
             # Trainer's own epoch loop: measured by a child process, so that nothing that goes wrong there (an abort
             # inside the runtime cannot be caught) takes the result line above with it
             extra = other_sections_in_child(args, B)

@@ -277,7 +277,7 @@ def test_training_step_at_bench_batch_against_oracle(name, B, T, size):
 
 
 def test_bf16_training_step_at_bench_batch():
-    """BASELINE configuration 4's arithmetic (bf16 MFMA operands, fp32 accumulation) on the full-width
+    """The bf16 configuration's arithmetic (bf16 MFMA operands, fp32 accumulation) on the full-width
     DisentangledVAE at 256 clips: stated tolerance against the fp64 oracle -- loss 2e-3 relative,
     reconstructions and latent means 2e-2 relative L2, per-tensor gradients 2e-1 relative L2 (operands of
     every product are rounded to 8 significand bits, forward and backward)."""

@@ -456,7 +456,7 @@ def test_gradsync_on_rccl_single_rank_equals_plain_step():
 
 
 def test_dp_graph_step_in_bf16_at_batch_256_equals_the_one_graph_step():
-    """The combination BASELINE's data-parallel configuration names, as one thing: the captured data-parallel step
+    """The data-parallel bf16 configuration as one thing: the captured data-parallel step
     (three graphs around the RCCL all-reduces, here on a one-rank group, where averaging is the identity) with bf16
     MFMA operands, full-width DisentangledVAE, 256 clips.  Three steps give the parameters of the one-graph bf16
     step bit for bit (same kernels in the same order; only the graph boundaries and the flat gradient buffer
