@@ -407,25 +407,6 @@ def other_sections(steps, warmup, batch, config_name='disentangled_simple.json')
     return out
 
 
-def other_sections_in_child(args, batch):
-    """other_sections() in a process of its own; its result dictionary, or a one-entry dictionary saying what
-    happened to the child."""
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), '--section', 'others', '--steps', str(args.steps),
-           '--warmup', str(args.warmup), '--batch', str(batch)]
-    try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=1500, text=True)      # (stderr passes through)
-    except subprocess.TimeoutExpired:
-        return {'other_sections_error': 'the child process did not finish within 1500 s'}
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-    if r.returncode != 0 or not lines:
-        return {'other_sections_error': f'the child process ended with status {r.returncode}'}
-    try:
-        return json.loads(lines[-1])
-    except ValueError as e:
-        return {'other_sections_error': f'unreadable result of the child process: {e}'}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -733,8 +714,16 @@ def main():
         # time the kernels it shares the chip with
         from hipvae import functional as _fn
         off_path, _fn.USE_OFF_PATH = _fn.USE_OFF_PATH, False
-        step(0)                      # untimed: the eager path's buffers come out of the allocator's cache afterwards
-        rows = trace_steps(step, 5, peak_tflops)
+        # ... and on the stream the captured step was warmed up on: autograd keeps each parameter's accumulation node
+        # with the stream it first ran on, and warns when a gradient arrives from another one
+        from hipvae.graph import capture_stream
+        side = capture_stream(dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step(0)                  # untimed: the eager path's buffers come out of the allocator's cache afterwards
+            rows = trace_steps(step, 5, peak_tflops)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
         _fn.USE_OFF_PATH = off_path
         top = next((r for r in rows if r['bound'] is not None), rows[0])
         traffic, traffic_src = pmc_traffic(top['kernel'])
@@ -785,9 +774,13 @@ def main():
         if args.config == 'disentangled_simple.json' and args.precision == 'fp32':
             # the reference's own batch-32 configurations (DisentangledVAE, LSTMVAE, fp32) and the small baseline beside
             # them, LSTMVAE at the headline's batch, the 128 x 128 x 40 configuration at batch 32, and the
-            # Trainer's own epoch loop: measured by a child process, so that nothing that goes wrong there (an abort
-            # inside the runtime cannot be caught) takes the result line above with it
-            extra = other_sections_in_child(args, B)
+            # Trainer's own epoch loop.  In this process: starting a child process from one that has initialised the GPU
+            # was seen to end in a segmentation fault inside the fork now and then (`--section others` runs these
+            # measurements alone).
+            try:
+                extra = other_sections(args.steps, args.warmup, B, args.config)
+            except Exception as e:                                          # noqa: BLE001
+                extra = {'other_sections_error': f'{type(e).__name__}: {e}'[:300]}
             result.update(extra)
             if 'trainer_epoch' in extra and 'error' not in extra['trainer_epoch'] and 'batch32_configs' in extra:
                 ring_rate = {B: result['value'], 32: extra['batch32_configs']['disentangled_simple.json']['value']}

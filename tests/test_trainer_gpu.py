@@ -649,12 +649,47 @@ def test_a_dead_graph_in_a_reference_cycle_does_not_abort_the_next_capture():
     """Python's cycle collector may run at any allocation.  If it destroys an old captured step while a new one is
     being captured the runtime refuses and the process aborts (seen in bench.py: a whole run lost in its last
     section); every capture of hipvae.graph therefore collects first and keeps the collector quiet until it has
-    ended.  tools/debug/gc_probe.py leaves three dead steps in reference cycles and runs the collector inside the
-    next captured region: 'ok' with the guard, abort (exit status 134) with `--unguarded`.  Run as a child process:
-    the failure mode is an abort, not an exception."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    probe = os.path.join(root, 'tools', 'debug', 'gc_probe.py')
-    r = subprocess.run([sys.executable, probe], capture_output=True, text=True, timeout=240)
-    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), (r.returncode, r.stderr[-2000:])
+    ended.  Here: three dead steps in reference cycles, then a capture: none of them may still exist when the captured
+    region runs, and the collector must be off inside it.  (tools/debug/gc_probe.py runs the collector inside the
+    captured region: 'ok' with the guard, exit status 134 with `--unguarded`.)"""
+    import gc
+    import weakref
+    import models
+    from hipvae import losses
+    from hipvae.graph import GraphedTrainStep
+    from hipvae.optim import FusedAdam
+    cfg = dict(content_dim=8, motion_dim=8, content_channels=[4, 8, 16, 32], motion_channels=[4, 8],
+               decoder_channels=[32, 16, 8, 4], content_feature_dim=32, motion_feature_dim=32, lstm_hidden=16,
+               lstm_layers=1, bidirectional=True, sequence_length=6)
+    seen = []
+
+    def make(dead_graphs=()):
+        m = models.DisentangledVAE(**cfg).cuda().train()
+        opt = FusedAdam(m.parameters(), lr=1e-3)
+        v = synthetic_clips(4, 6, 3).cuda()
+
+        def loss_of(mm, x):
+            if torch.cuda.is_current_stream_capturing():
+                seen.append((gc.isenabled(), [r() is not None for r in dead_graphs]))
+            return losses.disentangled_loss(mm(x), x, beta=1.0)
+        step = GraphedTrainStep(m, opt, loss_of, v)
+        step(v)
+        return step
+
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        dead = []
+        for _ in range(3):
+            step = make()
+            step.me = step                       # a cycle: only the collector can free it
+            dead.append(weakref.ref(step))
+            del step
+        assert dead[-1]() is not None             # (the earlier ones went when the next step collected before capturing)
+    finally:
+        if was:
+            gc.enable()
+    make(dead)
+    torch.cuda.synchronize()
+    assert seen and all(enabled is False and not any(alive) for enabled, alive in seen), seen
+    assert gc.isenabled() == was
