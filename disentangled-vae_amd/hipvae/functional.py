@@ -651,13 +651,15 @@ class _TwoLanes:
 
 class LSTMEncoder(torch.autograd.Function):
     """nn.LSTM(batch_first, bidirectional, num_layers) from zero state; returns cat of the last
-    layer's final hidden state per direction (models/encoders.py:156-173).
+    layer's final hidden state per direction (models/encoders.py:156-173) and, with want_all, also what nn.LSTM
+    itself returns: the last layer's output sequence [B, T, D*H] and (h_n, c_n) [L*D, B, H].  Gradients flow back
+    from the final state, the sequence and h_n; c_n is returned for inspection only (not differentiable).
 
     Weights come flat, per layer and direction: w_ih, w_hh, b_ih, b_hh.  Internally time-major.
     """
 
     @staticmethod
-    def forward(ctx, x: Tensor, num_layers: int, bidirectional: bool, *weights: Tensor):
+    def forward(ctx, x: Tensor, num_layers: int, bidirectional: bool, want_all: bool, *weights: Tensor):
         _need_gpu(x, 'LSTMEncoder')
         B, T, I0 = x.shape
         D = 2 if bidirectional else 1
@@ -702,24 +704,40 @@ class LSTMEncoder(torch.autograd.Function):
             final = last[T - 1].clone()
         ctx.layers = layers
         ctx.cfg = (B, T, I0, D, H, num_layers)
+        ctx.want_all = want_all
         ctx.save_for_backward(*weights)
-        return final
+        if not want_all:
+            return final
+        out_seq = ops.permute3(last, (T, B, D * H), (1, 0, 2))                      # [B, T, D*H]
+        # the chronologically last step of a chain: T-1 forward, 0 for the reverse direction
+        h_n = torch.stack([layers[l][1][0 if d == 1 else T - 1][:, d * H:(d + 1) * H]
+                           for l in range(num_layers) for d in range(D)])
+        c_n = torch.stack([layers[l][2][d, 0 if d == 1 else T - 1] for l in range(num_layers) for d in range(D)])
+        ctx.mark_non_differentiable(c_n)
+        return final, out_seq, h_n, c_n
 
     @staticmethod
-    def backward(ctx, dfinal: Tensor):
+    def backward(ctx, dfinal: Optional[Tensor], dseq: Optional[Tensor] = None, dh_n: Optional[Tensor] = None,
+                 dc_n: Optional[Tensor] = None):
         B, T, I0, D, H, L = ctx.cfg
         weights = ctx.saved_tensors
         grads = [None] * len(weights)
-        dfinal = dfinal.contiguous()
+        like = next(t for t in (dfinal, dseq, dh_n) if t is not None)
+        dfinal = dfinal.contiguous() if dfinal is not None else _zeros(B, D * H, like=like)
         dout = None                                    # gradient wrt this layer's output sequence
         for l in range(L - 1, -1, -1):
             inp, hseq, cseq, gates = ctx.layers[l]
             I = inp.shape[2]
             dh = dout if dout is not None else _zeros(T, B, D * H, like=dfinal)
             if l == L - 1:
+                if dseq is not None:
+                    dh += ops.permute3(dseq.contiguous(), (B, T, D * H), (1, 0, 2))
                 dh[T - 1][:, :H] += dfinal[:, :H]
                 if D == 2:
                     dh[0][:, H:] += dfinal[:, H:]
+            if dh_n is not None:
+                for d in range(D):
+                    dh[0 if d == 1 else T - 1][:, d * H:(d + 1) * H] += dh_n[l * D + d]
             dinp = None
             # the two directions' recurrences side by side, then the weight-gradient GEMMs in turn
             dgs = [_empty(T, B, 4 * H, like=dfinal) for _ in range(D)]
@@ -778,7 +796,7 @@ class LSTMEncoder(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.permute3(dout, (T, B, I0), (1, 0, 2))
-        return (dx, None, None, *grads)
+        return (dx, None, None, None, *grads)
 
 
 class LSTMDecoder(torch.autograd.Function):

@@ -104,8 +104,11 @@ class VideoEncoder(nn.Module):
 
 
 class LSTMEncoder(nn.Module):
-    """(Bi)directional LSTM whose result is the last layer's final hidden state(s)
-    (reference: models/encoders.py:128-173)."""
+    """(Bi)directional LSTM whose result is the last layer's final hidden state(s), or with return_sequence the
+    output sequence, and nn.LSTM's (h_n, c_n) beside either (reference: models/encoders.py:128-173).  A caller
+    that only uses the final state sets `return_states = False` and gets (None, None) for the states, which saves
+    the launches that gather them (the models of this package do)."""
+    return_states = True
 
     def __init__(self, input_dim: int = 512, hidden_dim: int = 256, num_layers: int = 1,
                  bidirectional: bool = True, dropout: float = 0.0):
@@ -128,10 +131,12 @@ class LSTMEncoder(nn.Module):
         return ws
 
     def forward(self, x: torch.Tensor, return_sequence: bool = False):
-        if return_sequence:
-            raise NotImplementedError("the HIP LSTM encoder returns final states only")
-        final = HF.LSTMEncoder.apply(x, self.num_layers, self.bidirectional, *self._flat_weights())
-        return final, (None, None)
+        if not (return_sequence or self.return_states):
+            final = HF.LSTMEncoder.apply(x, self.num_layers, self.bidirectional, False, *self._flat_weights())
+            return final, (None, None)
+        final, output, h_n, c_n = HF.LSTMEncoder.apply(x, self.num_layers, self.bidirectional, True,
+                                                       *self._flat_weights())
+        return (output if return_sequence else final), (h_n, c_n)
 
 
 class VAEEncoder(nn.Module):
@@ -199,6 +204,7 @@ class MotionEncoder(nn.Module):
         self.cnn_encoder = LightCNNEncoder(in_channels=in_channels, channels=channels, output_dim=feature_dim)
         self.lstm = LSTMEncoder(input_dim=feature_dim, hidden_dim=lstm_hidden, num_layers=lstm_layers,
                                 bidirectional=bidirectional)
+        self.lstm.return_states = False            # only the final state is used here
         self.vae_head = VAEEncoder(input_dim=self.lstm.output_dim, latent_dim=latent_dim)
 
     def compute_frame_differences(self, video: torch.Tensor) -> torch.Tensor:

@@ -25,6 +25,7 @@ class LSTMVAE(nn.Module):
         self.cnn_encoder = CNNEncoder(in_channels=in_channels, channels=encoder_channels, output_dim=feature_dim)
         self.lstm_encoder = LSTMEncoder(input_dim=feature_dim, hidden_dim=lstm_hidden, num_layers=lstm_layers,
                                         bidirectional=bidirectional, dropout=dropout)
+        self.lstm_encoder.return_states = False    # only the final state is used here
         self.vae_head = VAEEncoder(input_dim=self.lstm_encoder.output_dim, latent_dim=latent_dim)
         self.lstm_decoder = LSTMDecoder(input_dim=latent_dim, hidden_dim=lstm_hidden, output_dim=feature_dim,
                                         num_layers=lstm_layers, sequence_length=sequence_length, dropout=dropout)

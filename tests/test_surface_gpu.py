@@ -163,3 +163,38 @@ def test_efficiency_and_diversity_helpers():
     for r in res.values():
         assert {'mse', 'psnr', 'temporal_consistency', 'sample_variance', 'forward_time_ms',
                 'trainable_parameters'} <= set(r)
+
+
+@pytest.mark.parametrize('H', [16, 128])                       # per-step kernels / one launch per recurrence
+@pytest.mark.parametrize('layers,bidirectional', [(1, True), (2, True), (2, False)])
+def test_lstm_encoder_returns_what_nn_lstm_returns(H, layers, bidirectional):
+    """LSTMEncoder.forward(x, return_sequence) of the reference (models/encoders.py:156-173): the output sequence or
+    the final state, and (h_n, c_n) beside either; gradients from the sequence, the final state and h_n.  Against
+    torch's own nn.LSTM in fp64 on the CPU with the same weights."""
+    import copy
+    from models.encoders import LSTMEncoder
+    torch.manual_seed(3)
+    B, T, I = 3, 5, 12
+    enc = LSTMEncoder(input_dim=I, hidden_dim=H, num_layers=layers, bidirectional=bidirectional).cuda()
+    ref = copy.deepcopy(enc.lstm).double().cpu()
+    x = torch.randn(B, T, I)
+    xg, xr = x.cuda().requires_grad_(True), x.double().requires_grad_(True)
+    D = 2 if bidirectional else 1
+    w_seq, w_fin, w_h = torch.randn(B, T, D * H), torch.randn(B, D * H), torch.randn(layers * D, B, H)
+
+    out, (h_n, c_n) = enc(xg, return_sequence=True)
+    fin, (h_n2, c_n2) = enc(xg)
+    r_out, (r_h, r_c) = ref(xr)
+    r_fin = torch.cat([r_h[-2], r_h[-1]], dim=1) if bidirectional else r_h[-1]
+    for got, want in ((out, r_out), (h_n, r_h), (c_n, r_c), (fin, r_fin), (h_n2, r_h), (c_n2, r_c)):
+        assert got.shape == want.shape
+        torch.testing.assert_close(got.cpu().double(), want.detach(), rtol=2e-5, atol=2e-6)
+    ((out * w_seq.cuda()).sum() + (fin * w_fin.cuda()).sum() + (h_n * w_h.cuda()).sum()).backward()
+    ((r_out * w_seq.double()).sum() + (r_fin * w_fin.double()).sum() + (r_h * w_h.double()).sum()).backward()
+    torch.testing.assert_close(xg.grad.cpu().double(), xr.grad, rtol=1e-4, atol=1e-5)
+    for (n, p), (_, q) in zip(enc.lstm.named_parameters(), ref.named_parameters()):
+        torch.testing.assert_close(p.grad.cpu().double(), q.grad, rtol=1e-4, atol=1e-5, msg=n)
+    # the economy switch the models use: states not gathered
+    enc.return_states = False
+    fin3, states = enc(xg)
+    assert states == (None, None) and torch.equal(fin3, fin)
