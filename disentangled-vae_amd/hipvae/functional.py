@@ -68,7 +68,21 @@ def _seq_ok(chains: int, T: int, B: int, H: int) -> bool:
     return True
 
 
+def _seq_groups(D: int, T: int, B: int, H: int):
+    """How the D directions of a recurrence share out over one-launch kernels: [[0, 1]] (one launch), [[0], [1]]
+    (one launch per direction, when both together would exceed what may be resident), or None (per-step kernels)."""
+    if _seq_ok(D, T, B, H):
+        return [list(range(D))]
+    if D == 2 and _seq_ok(1, T, B, H):
+        return [[0], [1]]
+    return None
+
+
 def _several_ranks() -> bool:
+    """(DVAE_ASSUME_SEVERAL_RANKS=1: the kernel choices of a multi-rank job in a single process, for measuring them
+    on one GPU)"""
+    if os.environ.get('DVAE_ASSUME_SEVERAL_RANKS') == '1':
+        return True
     return (torch.distributed.is_available() and torch.distributed.is_initialized()
             and torch.distributed.get_world_size() > 1)
 
@@ -676,12 +690,16 @@ class LSTMEncoder(torch.autograd.Function):
             ws = [[w.detach() for w in weights[(l * D + d) * 4:(l * D + d) * 4 + 4]] for d in range(D)]
             xproj = [ops.gemm_nt(inp.view(T * B, I), ws[d][0].contiguous()).view(T, B, 4 * H) for d in range(D)]
             w_hh = [ws[d][1].contiguous() for d in range(D)]
-            if _seq_ok(D, T, B, H):
-                # the whole recurrence of both directions in one launch, recurrent weights in registers
-                ops.lstm_seq_fwd([dict(xproj=xproj[d], w_rec=w_hh[d], b_a=ws[d][2].contiguous(),
-                                       b_b=ws[d][3].contiguous(), gates=gates[d],
-                                       hseq=hseq[:, :, d * H:(d + 1) * H], cseq=cseq[d], reverse=(d == 1))
-                                  for d in range(D)], T, B, H)
+            # the whole recurrence of both directions in one launch, recurrent weights in registers; where the two
+            # chains together exceed what may be resident (several ranks: room is left for the collectives' kernels),
+            # one launch per direction, one after the other
+            groups = _seq_groups(D, T, B, H)
+            if groups is not None:
+                for ds in groups:
+                    ops.lstm_seq_fwd([dict(xproj=xproj[d], w_rec=w_hh[d], b_a=ws[d][2].contiguous(),
+                                           b_b=ws[d][3].contiguous(), gates=gates[d],
+                                           hseq=hseq[:, :, d * H:(d + 1) * H], cseq=cseq[d], reverse=(d == 1))
+                                      for d in ds], T, B, H)
                 layers.append((inp, hseq, cseq, gates))
                 inp = hseq
                 continue
@@ -743,12 +761,14 @@ class LSTMEncoder(torch.autograd.Function):
             dgs = [_empty(T, B, 4 * H, like=dfinal) for _ in range(D)]
             dcs = [[_empty(B, H, like=dfinal), _empty(B, H, like=dfinal)] for _ in range(D)]
             w_hhs = [weights[(l * D + d) * 4 + 1].contiguous() for d in range(D)]
-            seq = _seq_ok(D, T, B, H)
+            groups = _seq_groups(D, T, B, H)
+            seq = groups is not None
             if seq:
-                # both directions' chains in one launch, recurrent weights in registers
-                ops.lstm_seq_bwd([dict(w_rec=w_hhs[d], gates=gates[d], cseq=cseq[d],
-                                       dh_ext=dh[:, :, d * H:(d + 1) * H], dgates=dgs[d], reverse=(d == 1))
-                                  for d in range(D)], T, B, H)
+                # both directions' chains in one launch (or one launch each, see forward), recurrent weights in registers
+                for ds in groups:
+                    ops.lstm_seq_bwd([dict(w_rec=w_hhs[d], gates=gates[d], cseq=cseq[d],
+                                           dh_ext=dh[:, :, d * H:(d + 1) * H], dgates=dgs[d], reverse=(d == 1))
+                                      for d in ds], T, B, H)
             w_hh_t = [] if seq else [w.t().contiguous() for w in w_hhs]   # [H, 4H]: k-contiguous rows for dh = dG * W_hh
             with _TwoLanes(dfinal, D == 2 and not seq) as lanes:
                 for i in (() if seq else range(T - 1, -1, -1)):   # walk the recurrences backwards

@@ -198,3 +198,39 @@ def test_lstm_encoder_returns_what_nn_lstm_returns(H, layers, bidirectional):
     enc.return_states = False
     fin3, states = enc(xg)
     assert states == (None, None) and torch.equal(fin3, fin)
+
+
+def test_recurrence_under_the_several_ranks_limit_is_one_launch_per_direction(monkeypatch):
+    """With several ranks the one-launch recurrence kernels may hold one workgroup per compute unit (the collectives'
+    kernels need room), which the two directions of the motion encoder at batch 256 exceed together: they then run
+    as one launch each instead of falling back to one launch per step.  Same bits either way."""
+    from hipvae import functional as HF, ops
+    from models.encoders import LSTMEncoder
+    torch.manual_seed(5)
+    B, T, I, H = 256, 19, 64, 256
+    enc = LSTMEncoder(input_dim=I, hidden_dim=H, num_layers=1, bidirectional=True).cuda()
+    x = torch.randn(B, T, I, device='cuda')
+    w = torch.randn(B, 2 * H, device='cuda')
+
+    def run():
+        calls = []
+        plain_f, plain_b = ops.lstm_seq_fwd, ops.lstm_seq_bwd
+        monkeypatch.setattr(ops, 'lstm_seq_fwd', lambda chains, *a: (calls.append(('f', len(chains))), plain_f(chains, *a))[1])
+        monkeypatch.setattr(ops, 'lstm_seq_bwd', lambda chains, *a: (calls.append(('b', len(chains))), plain_b(chains, *a))[1])
+        enc.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        fin, _ = enc(xg)
+        (fin * w).sum().backward()
+        monkeypatch.setattr(ops, 'lstm_seq_fwd', plain_f)
+        monkeypatch.setattr(ops, 'lstm_seq_bwd', plain_b)
+        return calls, fin.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in enc.parameters()]
+
+    assert HF._seq_groups(2, T, B, H) == [[0, 1]]
+    calls1, fin1, dx1, g1 = run()
+    assert calls1 == [('f', 2), ('b', 2)]
+    monkeypatch.setattr(HF, '_several_ranks', lambda: True)
+    assert HF._seq_groups(2, T, B, H) == [[0], [1]]
+    calls2, fin2, dx2, g2 = run()
+    assert calls2 == [('f', 1), ('f', 1), ('b', 1), ('b', 1)]
+    assert torch.equal(fin1, fin2) and torch.equal(dx1, dx2) and all(torch.equal(a, b) for a, b in zip(g1, g2))
+    ops.check_lstm_seq_timeouts()
