@@ -429,7 +429,7 @@ def main():
                     help='initialise the RCCL process group and use the data-parallel step even with one rank '
                          '(exercises the multi-GPU code path on a single GPU)')
     ap.add_argument('--section', default='', choices=['', 'others'],
-                    help="'others': only the measurements beside the headline (what the default run asks of a child process)")
+                    help="'others': only the measurements beside the headline")
     ap.add_argument('--trainer', action='store_true',
                     help='measure Trainer.train_epoch() + validate() (what the CLI runs: 10,000 / 1,000 generated clips) '
                          'at batch 32 and at --batch instead of the device-resident ring, and print that as the line')
@@ -437,6 +437,8 @@ def main():
                     'overlapped with backward); otherwise replay the captured step (several ranks: two hipGraphs '
                     'around one gradient all-reduce)')
     args = ap.parse_args()
+    import faulthandler
+    faulthandler.enable()            # a crash inside native code leaves the Python stacks of all threads on stderr
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))

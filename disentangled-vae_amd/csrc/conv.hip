@@ -223,6 +223,24 @@ __device__ __forceinline__ void st4s(float* base, int64_t o, const f32x4& v, boo
   }
 }
 
+// Order of the K tiles when a K tile never straddles two filter taps (Cin % 32 == 0): blocks of 32 input channels
+// outermost, the filter taps inside a block.  A frame's pixel is read by four taps (by four output pixels); taps
+// outermost, those four reads of one 128-byte piece lie a whole pass over the tile's input apart (64-256 KB per
+// workgroup, more than its share of L2) and the layer's input crosses the fabric three to four times.  Inside a
+// block the conv's sixteen taps go by parity class (kh & 1, kw & 1), the four taps of a class touching the same
+// pixels, so the re-reads come within four K tiles.  Operand B follows through conv_walk_k0.
+template <int MODE>
+__device__ __forceinline__ int conv_walk_tap(int kt) {
+  if (MODE == 1) return kt & 3;
+  return (int)((0xFD75EC64B931A820ull >> (4 * (kt & 15))) & 15u);      // 0 2 8 10 | 1 3 9 11 | 4 6 12 14 | 5 7 13 15
+}
+template <int MODE>
+__device__ __forceinline__ int conv_walk_block(int kt) { return MODE == 1 ? kt >> 2 : kt >> 4; }
+template <int MODE>
+__device__ __forceinline__ int conv_walk_k0(const ConvArgs& g, int kt) {
+  return g.cin32 ? conv_walk_tap<MODE>(kt) * g.Cin + conv_walk_block<MODE>(kt) * 32 : kt * 32;
+}
+
 // A operand of the forward implicit GEMMs.  MODE 0: conv (16 taps, input pixel 2*o-1+k);
 // MODE 1: transposed conv phase (4 taps, input pixel a+ph-th).  C1: single input channel.
 //
@@ -230,8 +248,7 @@ __device__ __forceinline__ void st4s(float* base, int64_t o, const f32x4& v, boo
 // and one bit per filter tap saying whether that tap falls inside the frame.  A K tile then costs a
 // bit test and one address add per 16-byte load.  issue() only starts loads (masked-out chunks read
 // x[0..3], which is always there, and are zeroed in finish()); the BatchNorm scale/shift of the K
-// tile's channels ride along as two more loads in flight.  K tiles must be visited in order, from the one
-// given to seek() (0 by default).
+// tile's channels ride along as two more loads in flight.  K tiles may be visited in any order.
 template <int V4, int MODE, bool C1>
 struct ConvALoader {
   const ConvArgs& g;
@@ -239,12 +256,9 @@ struct ConvALoader {
   int64_t off0[V4];       // element offset of (n, h0, w0, channel 0)
   unsigned tapmask[V4];
   int h0[V4], w0[V4];     // single-channel path only
-  int tap, ci0;           // position of the current K tile (uniform path)
-  int kt0;                // first K tile of the walk
   unsigned mask;
   float4 sc, sh;
-  __device__ __forceinline__ ConvALoader(const ConvArgs& g_, int ph_, int pw_) : g(g_), ph(ph_), pw(pw_), kt0(0) {}
-  __device__ __forceinline__ void seek(int kt_first) { kt0 = kt_first; }
+  __device__ __forceinline__ ConvALoader(const ConvArgs& g_, int ph_, int pw_) : g(g_), ph(ph_), pw(pw_) {}
   __device__ __forceinline__ void set_tile(int64_t m0) {
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
@@ -306,19 +320,8 @@ struct ConvALoader {
     int tp, ci;
     bool kok;
     if (g.cin32) {
-      if (kt == kt0) {
-        const int k0 = kt * 32;
-        tap = g.lc >= 0 ? k0 >> g.lc : k0 / g.Cin;
-        ci0 = k0 - tap * g.Cin;
-      } else {
-        ci0 += 32;
-        if (ci0 >= g.Cin) {
-          ci0 = 0;
-          ++tap;
-        }
-      }
-      tp = tap;
-      ci = ci0 + 4 * ch;
+      tp = conv_walk_tap<MODE>(kt);
+      ci = conv_walk_block<MODE>(kt) * 32 + 4 * ch;
       kok = kt * 32 < g.K;
     } else {
       const int k = kt * 32 + 4 * ch;
@@ -370,6 +373,20 @@ struct ConvALoader {
   }
 };
 
+// B operand (packed filter [Cout][K]) read in the K order of the A operand
+template <int V4, int MODE>
+struct ConvBLoader {
+  KCLoader<V4> l;
+  const ConvArgs& g;
+  __device__ __forceinline__ ConvBLoader(const ConvArgs& g_, const float* base, int64_t n0)
+      : l(base, (int64_t)g_.K, (int64_t)g_.Cout, (int64_t)g_.K, n0), g(g_) {}
+  __device__ __forceinline__ void issue(int kt, f32x4 (&r)[V4]) { l.issue_at(conv_walk_k0<MODE>(g, kt), r); }
+  __device__ __forceinline__ void finish(f32x4 (&r)[V4]) const { l.finish(r); }
+  typedef typename KCLoader<V4>::Tag Tag;
+  __device__ __forceinline__ Tag tag() const { return l.tag(); }
+  __device__ __forceinline__ void set_tag(const Tag& t) { l.set_tag(t); }
+};
+
 template <class T, int MODE, bool C1, int BF, bool BNS>      // BF: PREC_F32, PREC_BF16 or PREC_SPLIT
 __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * Core<T, BF>::STAGE];
@@ -384,15 +401,23 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
     phase = j & 3;
     bx = (j >> 2) * 8 + x;
   }
+  // conv with several column tiles: the column tiles of one M tile read the same input; numbered eight apart they
+  // run on one XCD next to each other instead of a whole grid row of workgroups apart
+  int by = (int)blockIdx.y;
+  if (MODE == 0 && gridDim.y > 1 && (gx & 7) == 0) {
+    const unsigned id = blockIdx.x + (unsigned)gx * blockIdx.y, slot = id >> 3;
+    by = (int)(slot % gridDim.y);
+    bx = (int)(slot / gridDim.y) * 8 + (int)(id & 7);
+  }
   const int ph = phase >> 1, pw = phase & 1;
-  const int64_t n0 = (int64_t)blockIdx.y * T::BN;
+  const int64_t n0 = (int64_t)by * T::BN;
   const int ktiles = (g.K + 31) / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / T::WGN, wn = wave % T::WGN;
   const int l31 = lane & 31;
 
   ConvALoader<T::A_V4, MODE, C1> la(g, ph, pw);
-  KCLoader<T::B_V4> lb(g.wp + (int64_t)phase * g.Cout * g.K, (int64_t)g.K, (int64_t)g.Cout, (int64_t)g.K, n0);
+  ConvBLoader<T::B_V4, MODE> lb(g, g.wp + (int64_t)phase * g.Cout * g.K, n0);
 
   float s1[T::TN], s2[T::TN];
 #pragma unroll
@@ -401,7 +426,6 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
   const int kt_begin = split ? (int)blockIdx.z * g.kt_per : 0;
   const int kt_end = split ? (kt_begin + g.kt_per < ktiles ? kt_begin + g.kt_per : ktiles) : ktiles;
   float* const yout = split ? g.slab + (int64_t)blockIdx.z * g.slab_stride : g.y;
-  la.seek(kt_begin);
 
   for (int mt = g.mt0 + bx; mt < g.mtiles; mt += gx) {
     const int64_t m0 = (int64_t)mt * T::BM;

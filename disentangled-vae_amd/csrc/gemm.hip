@@ -19,6 +19,7 @@ struct GemmArgs {
   int act, accumulate, ktiles_per_split;
   int tm0;      // first row of tiles of this launch (a product may be split over two launches)
   int wide_rows;  // rows of the output (and of the partial slabs) may be written 16 bytes at a time
+  int group_n;    // the column tiles of one row of tiles (and K range) run on one XCD, next to each other
 };
 
 // Diagnostic build only (-DDVAE_GEMM_STAMP=1, never the shipped library): every workgroup's shader-clock and
@@ -44,9 +45,24 @@ __global__ void __launch_bounds__(256, (DVAE_GEMM_ONE_STAGE && KIND == G_NT && B
   constexpr int TILE_FLOATS = T::BM * (T::BN + 4);
   constexpr int SMEM_FLOATS = (BF == PREC_BF16 && TILE_FLOATS > LOOP_FLOATS) ? TILE_FLOATS : LOOP_FLOATS;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
-  const int64_t m0 = (int64_t)(blockIdx.y + g.tm0) * T::BM, n0 = (int64_t)blockIdx.x * T::BN;
+  // Workgroups go to the eight XCDs in turn (linear id mod 8) and every XCD has its own L2.  Numbered as launched,
+  // the few column tiles that share one A tile land on different XCDs and each fetches that tile for itself; with
+  // group_n they are numbered eight apart instead: (row of tiles, K range) g = 8 * (slot / columns) + XCD, column =
+  // slot % columns.  Groups beyond the last multiple of eight keep the plain numbering.
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g.group_n) {
+    const unsigned tn = gridDim.x, groups = gridDim.y * gridDim.z;
+    const unsigned id = blockIdx.x + tn * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (id < (groups & ~7u) * tn) {
+      const unsigned slot = id >> 3, grp = (slot / tn) * 8 + (id & 7);
+      bx = slot % tn;
+      by = grp % gridDim.y;
+      bz = grp / gridDim.y;
+    }
+  }
+  const int64_t m0 = (int64_t)(by + g.tm0) * T::BM, n0 = (int64_t)bx * T::BN;
   const int ktiles = (int)((g.K + 31) / 32);
-  const int kt_begin = blockIdx.z * g.ktiles_per_split;
+  const int kt_begin = bz * g.ktiles_per_split;
   int kt_end = kt_begin + g.ktiles_per_split;
   if (kt_end > ktiles) kt_end = ktiles;
 
@@ -89,7 +105,7 @@ __global__ void __launch_bounds__(256, (DVAE_GEMM_ONE_STAGE && KIND == G_NT && B
   // the store instructions, 512 contiguous bytes per row and wave instruction.  Same values, same arithmetic.
   constexpr int TLD = T::BN + 4;
   constexpr bool fits = SMEM_FLOATS >= T::BM * TLD;
-  float* dst = g.slab ? g.slab + (int64_t)blockIdx.z * g.M * g.N : g.C;
+  float* dst = g.slab ? g.slab + (int64_t)bz * g.M * g.N : g.C;
   const int64_t ldd = g.slab ? g.N : g.ldc;
   const bool wide = fits && g.wide_rows && m0 + T::BM <= g.M && n0 + T::BN <= g.N;
   if (wide) {
@@ -285,6 +301,17 @@ static int choose_split(int64_t tiles, int64_t ktiles, int64_t mn) {
   return best;
 }
 
+// Whether the column tiles of a row of tiles should share an XCD (GemmArgs::group_n), by the operand bytes that
+// cross the fabric either way: numbered as launched, A is fetched by min(columns, 8) XCDs and B by 8 / columns of
+// them; grouped, A is fetched once and B by all eight, once per round of 512 workgroups.
+static bool group_column_tiles(int64_t M, int64_t N, int64_t K, int64_t tn, int64_t workgroups) {
+  static const bool off = [] { const char* v = getenv("DVAE_GEMM_GROUP_N"); return v && v[0] == '0'; }();
+  if (off || tn < 2 || tn > 8) return false;
+  const double a = (double)M * (double)K, b = (double)N * (double)K;
+  const double rounds = (double)ceil_div64(workgroups, 512);
+  return a + 8.0 * rounds * b < a * (double)tn + b * (8.0 / (double)tn);
+}
+
 struct Plan {
   bool small_m;
   int64_t tm, tn;
@@ -382,7 +409,10 @@ static int launch_gemm(const char* name, GemmArgs g, float* ws, hipStream_t stre
                       1.08 * 0.5 * (double)half_rounds < 0.95 * (double)wide_rounds;
   if (p.small_m) GEMM_LAUNCH(Skinny, KIND, grid)
   else if (narrow) GEMM_LAUNCH(Half, KIND, dim3((unsigned)ceil_div64(g.N, 64), (unsigned)p.tm, 1))
-  else GEMM_LAUNCH(Big, KIND, grid)
+  else {
+    g.group_n = group_column_tiles(g.M, g.N, g.K, p.tn, p.tn * p.tm * p.split);
+    GEMM_LAUNCH(Big, KIND, grid)
+  }
 #undef GEMM_LAUNCH
   DVAE_LAUNCH_CHECK(name);
   if (p.split > 1) {

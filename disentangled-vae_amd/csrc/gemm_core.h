@@ -569,8 +569,9 @@ struct KCLoader {
       rowok |= (unsigned)ok << v;
     }
   }
-  __device__ __forceinline__ void issue(int kt, f32x4 (&r)[V4]) {
-    const int k0 = kt * 32;
+  __device__ __forceinline__ void issue(int kt, f32x4 (&r)[V4]) { issue_at(kt * 32, r); }
+  // the K tile that starts at k0 (callers that walk K in an order of their own)
+  __device__ __forceinline__ void issue_at(int k0, f32x4 (&r)[V4]) {
     mask = (k0 + kofs < K) ? rowok : 0u;
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
