@@ -5,6 +5,10 @@
 #define ST(s) ((hipStream_t)(s))
 
 enum { G_NT = 0, G_NN = 1, G_TN = 2 };
+// bf16 operands: three workgroups per CU (the output tile leaves through LDS in two runs of rows)
+#ifndef DVAE_BF16_WG3
+#define DVAE_BF16_WG3 1
+#endif
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -38,12 +42,13 @@ extern "C" int dvae_debug_read_stamps(unsigned long long* host, int n) {
 #endif
 
 template <class T, int KIND, int BF>      // BF: PREC_F32 / PREC_BF16 / PREC_SPLIT
-__global__ void __launch_bounds__(256, (DVAE_GEMM_ONE_STAGE && KIND == G_NT && BF == PREC_F32) ? 3 : 2) gemm_kernel(GemmArgs g) {
-  // the K loop's stages, or the output tile on its way out (bf16 stages are smaller than the tile: 68 KB then,
-  // still two workgroups per CU)
+__global__ void __launch_bounds__(256, ((DVAE_GEMM_ONE_STAGE && KIND == G_NT && BF == PREC_F32) || (BF == PREC_BF16 && DVAE_BF16_WG3)) ? 3 : 2) gemm_kernel(GemmArgs g) {
+  // the K loop's stages, which also carry the output tile on its way out: whole when it fits, else in EPI_PASSES
+  // runs of rows (the bf16 stages are 40 KB, the 128 x 128 tile 68 KB: two runs, and a third workgroup per CU)
   constexpr int LOOP_FLOATS = ((DVAE_GEMM_ONE_STAGE && KIND == G_NT) ? 1 : 2) * Core<T, BF>::STAGE;
   constexpr int TILE_FLOATS = T::BM * (T::BN + 4);
-  constexpr int SMEM_FLOATS = (BF == PREC_BF16 && TILE_FLOATS > LOOP_FLOATS) ? TILE_FLOATS : LOOP_FLOATS;
+  constexpr int EPI_PASSES = (BF == PREC_BF16 && DVAE_BF16_WG3 && TILE_FLOATS > LOOP_FLOATS) ? 2 : 1;
+  constexpr int SMEM_FLOATS = (BF == PREC_BF16 && TILE_FLOATS / EPI_PASSES > LOOP_FLOATS) ? TILE_FLOATS / EPI_PASSES : LOOP_FLOATS;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   // Workgroups go to the eight XCDs in turn (linear id mod 8) and every XCD has its own L2.  Numbered as launched,
   // the few column tiles that share one A tile land on different XCDs and each fetches that tile for itself; with
@@ -104,32 +109,39 @@ __global__ void __launch_bounds__(256, (DVAE_GEMM_ONE_STAGE && KIND == G_NT && B
   // tile goes through the (now free) LDS stages instead and leaves as 16-byte stores along the rows: a quarter of
   // the store instructions, 512 contiguous bytes per row and wave instruction.  Same values, same arithmetic.
   constexpr int TLD = T::BN + 4;
-  constexpr bool fits = SMEM_FLOATS >= T::BM * TLD;
+  constexpr int RUN = T::BM / EPI_PASSES;                 // rows of the tile that travel through LDS together
+  constexpr bool fits = SMEM_FLOATS >= RUN * TLD;
   float* dst = g.slab ? g.slab + (int64_t)bz * g.M * g.N : g.C;
   const int64_t ldd = g.slab ? g.N : g.ldc;
   const bool wide = fits && g.wide_rows && m0 + T::BM <= g.M && n0 + T::BN <= g.N;
   if (wide) {
-    for_each_acc<T>(acc, [&](int r, int c, float v) { smem[r * TLD + c] = v; });
-    __syncthreads();
-    constexpr int C4 = T::BN / 4, PER = T::BM * C4 / 256;
+    constexpr int C4 = T::BN / 4, PER = RUN * C4 / 256;
     static_assert(256 % C4 == 0, "a thread keeps its columns for every piece it writes");
     const int c4 = threadIdx.x % C4;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!g.slab && g.bias) bias4 = *reinterpret_cast<const float4*>(g.bias + n0 + 4 * c4);
 #pragma unroll
-    for (int it = 0; it < PER; ++it) {
-      const int row = (it * 256 + threadIdx.x) / C4;
-      float4 o = *reinterpret_cast<const float4*>(smem + row * TLD + 4 * c4);
-      float4* p = reinterpret_cast<float4*>(dst + (m0 + row) * ldd + n0 + 4 * c4);
-      if (!g.slab) {
-        o.x += bias4.x; o.y += bias4.y; o.z += bias4.z; o.w += bias4.w;
-        if (g.act == DVAE_ACT_LRELU) { o.x = lrelu(o.x); o.y = lrelu(o.y); o.z = lrelu(o.z); o.w = lrelu(o.w); }
-        if (g.accumulate) {
-          const float4 q = *p;
-          o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+    for (int pass = 0; pass < EPI_PASSES; ++pass) {
+      if (pass > 0) __syncthreads();
+      for_each_acc<T>(acc, [&](int r, int c, float v) {
+        if (EPI_PASSES == 1 || r / RUN == pass) smem[(r - pass * RUN) * TLD + c] = v;
+      });
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < PER; ++it) {
+        const int row = (it * 256 + threadIdx.x) / C4;
+        float4 o = *reinterpret_cast<const float4*>(smem + row * TLD + 4 * c4);
+        float4* p = reinterpret_cast<float4*>(dst + (m0 + pass * RUN + row) * ldd + n0 + 4 * c4);
+        if (!g.slab) {
+          o.x += bias4.x; o.y += bias4.y; o.z += bias4.z; o.w += bias4.w;
+          if (g.act == DVAE_ACT_LRELU) { o.x = lrelu(o.x); o.y = lrelu(o.y); o.z = lrelu(o.z); o.w = lrelu(o.w); }
+          if (g.accumulate) {
+            const float4 q = *p;
+            o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+          }
         }
+        *p = o;
       }
-      *p = o;
     }
   } else if (g.slab) {
     for_each_acc<T>(acc, [&](int r, int c, float v) {
@@ -284,15 +296,17 @@ static bool small_gemm_shape(int64_t M, int64_t N, int64_t K) {
 // costs (rounds of 512) x (k-tiles per workgroup); each split adds a pass over the M x N partials,
 // priced in the same unit: one round of one k-tile is ~0.54 GFLOP ~ 4.9 us, which is the time HBM
 // needs for ~5 M floats of slab traffic.
-static int choose_split(int64_t tiles, int64_t ktiles, int64_t mn) {
-  if (tiles >= 512) return 1;
+static int choose_split(int64_t tiles, int64_t ktiles, int64_t mn, int64_t slots) {
+  if (tiles >= slots) return 1;
+  // floats of slab traffic that cost as much as one round of one k-tile (with bf16 operands a k-tile is ~1.2 us)
+  const double slab_unit = slots > 512 ? 1.2e6 : 5.0e6;
   int64_t smax = ktiles / 4;
   if (smax > 32) smax = 32;
   int best = 1;
   double best_cost = (double)ktiles;            // one round, no partials
   for (int64_t s = 2; s <= smax; ++s) {
-    const int64_t rounds = (tiles * s + 511) / 512;
-    const double cost = (double)rounds * (double)((ktiles + s - 1) / s) + (double)(s + 1) * (double)mn / 5.0e6;
+    const int64_t rounds = (tiles * s + slots - 1) / slots;
+    const double cost = (double)rounds * (double)((ktiles + s - 1) / s) + (double)(s + 1) * (double)mn / slab_unit;
     if (cost < best_cost * 0.9) {
       best_cost = cost;
       best = (int)s;
@@ -318,6 +332,9 @@ struct Plan {
   int split, ktiles_per_split;
 };
 
+// workgroups the chip holds at a time: two per CU, three with bf16 operands (smaller LDS stages)
+static int64_t resident_slots() { return (DVAE_BF16_WG3 && dvae_mfma_precision() == DVAE_PRECISION_BF16) ? 768 : 512; }
+
 static Plan make_plan(int64_t M, int64_t N, int64_t K) {
   Plan p;
   p.small_m = M <= 32;
@@ -325,7 +342,7 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K) {
   p.tm = ceil_div64(M, BM);
   p.tn = ceil_div64(N, BN);
   const int64_t ktiles = ceil_div64(K, 32);
-  p.split = choose_split(p.tm * p.tn, ktiles, M * N);
+  p.split = choose_split(p.tm * p.tn, ktiles, M * N, resident_slots());
   p.ktiles_per_split = (int)ceil_div64(ktiles, p.split);
   p.split = (int)ceil_div64(ktiles, p.ktiles_per_split);
   return p;
