@@ -439,6 +439,11 @@ def main():
     args = ap.parse_args()
     import faulthandler
     faulthandler.enable()            # a crash inside native code leaves the Python stacks of all threads on stderr
+    # this process captures a dozen steps one after the other: none of their graphs is destroyed before it ends
+    # (see hipvae.graph.keep_graphs_alive; DVAE_BENCH_DROP_GRAPHS=1 lets them go as their sections end)
+    if os.environ.get('DVAE_BENCH_DROP_GRAPHS') != '1':
+        from hipvae.graph import keep_graphs_alive
+        keep_graphs_alive()
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))

@@ -40,6 +40,26 @@ def quiet_collector():
             gc.enable()
 
 
+_KEPT = None
+
+
+def keep_graphs_alive(on: bool = True):
+    """From now on every graph captured here stays alive (with its memory pool) until the process ends or this is
+    switched off.  For a process that captures many steps one after the other (a benchmark over several
+    configurations): the runtime gives every instantiated graph a few streams of its own and takes them away when
+    the graph is destroyed; hardware queues are handed to streams by use count, and it is the taking away that
+    lets the counts drift apart until two streams of a new graph share the launch stream's queue, which
+    hipGraphLaunch of ROCm 7.0 does not survive (it walks off the end of the graph's stream list)."""
+    global _KEPT
+    _KEPT = [] if on else None
+
+
+def _keep(graph):
+    if _KEPT is not None:
+        _KEPT.append(graph)
+    return graph
+
+
 def capture_stream(device=None) -> torch.cuda.Stream:
     """The one stream per device on which every step is warmed up and captured.  Autograd keeps the
     gradient-accumulation node it made for a parameter, together with the stream it first ran on, for as long
@@ -120,6 +140,7 @@ class GraphedTrainStep:
         with quiet_collector(), torch.cuda.graph(self.graph, stream=self._capture_stream,
                                                  capture_error_mode='thread_local'):
             self.losses = self._step()
+        _keep(self.graph)
 
     def _before_replay(self, video: torch.Tensor):
         self.static_video.copy_(video, non_blocking=True)
@@ -169,6 +190,7 @@ class GraphedForward:
         with quiet_collector(), torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local'), \
                 torch.no_grad():
             self.out = self.fn(model, self.static_in)
+        _keep(self.graph)
 
     def __call__(self, batch: torch.Tensor):
         self.static_in.copy_(batch, non_blocking=True)
@@ -280,6 +302,8 @@ class GraphedDataParallelStep(GraphedTrainStep):
             if self.clip > 0:
                 self.opt.clip_grad_norm_(self.clip, fold_into_step=True)
             self.opt.step()
+        for g in [self.graph, self.graph_update] + self.stage_graphs:
+            _keep(g)
 
     def __call__(self, video: torch.Tensor):
         self._before_replay(video)
