@@ -12,6 +12,7 @@ Values baked into the graph: shapes and the other loss weights.
 """
 import contextlib
 import gc
+import os
 from typing import Callable, Dict, Optional
 
 import torch
@@ -40,7 +41,7 @@ def quiet_collector():
             gc.enable()
 
 
-_KEPT = None
+_KEPT = [] if os.environ.get('DVAE_KEEP_GRAPHS') == '1' else None      # see keep_graphs_alive
 
 
 def keep_graphs_alive(on: bool = True):
