@@ -192,6 +192,29 @@ def test_gemm_split_precision_is_fp32_accurate(ops, M, N, K):
     assert e_nn < 2e-6 and e_tn < 2e-6, (e_nn, e_tn)
 
 
+@pytest.mark.parametrize('M,N,K', [(2560, 256, 128), (2500, 384, 256), (1300, 640, 96)])
+def test_gemm_with_column_tiles_grouped_per_xcd(ops, M, N, K):
+    """A tall product with two to five column tiles per row of tiles takes the tile numbering that puts the column
+    tiles of one row of tiles on one XCD (20 groups of tiles: sixteen renumbered, four as launched; 11: eight and
+    three): every tile is still computed exactly once, in all three operand layouts and in bf16 mode, whose
+    kernels hold three workgroups per CU and send the output tile through LDS in two runs of rows."""
+    a, b, bias = rnd(M, K, seed=31), rnd(N, K, seed=32), rnd(N, seed=33)
+    ref = O.leaky_relu(a @ b.t() + bias)
+    assert rel_err(ops.gemm_nt(dev(a), dev(b), dev(bias), ops.ACT_LRELU), ref) < 2e-6
+    dy, w = rnd(M, N, seed=34), rnd(N, K, seed=35)                      # dx = dy w: K plays N here
+    assert rel_err(ops.gemm_nn(dev(dy), dev(w)), dy @ w) < 2e-6
+    if M % 4 == 0:
+        at, bt = rnd(K * 8, M, seed=36), rnd(K * 8, N, seed=37)        # a long K over few tiles: split-K as well
+        assert rel_err(ops.gemm_tn(dev(at), dev(bt)), at.t() @ bt) < 2e-6
+    ops.set_precision('bf16')
+    try:
+        got = ops.gemm_nt(dev(a), dev(b), dev(bias), ops.ACT_LRELU)
+    finally:
+        ops.set_precision('fp32')
+    a16, b16 = a.bfloat16().float(), b.bfloat16().float()
+    assert rel_err(got, O.leaky_relu(a16 @ b16.t() + bias)) < 2e-6
+
+
 def test_gemm_strided_views(ops):
     # operands that are column slices of wider matrices (row stride != width)
     big = dev(rnd(40, 96, seed=17))
