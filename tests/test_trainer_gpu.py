@@ -645,7 +645,7 @@ def test_graphed_forward_replays_the_eval_forward():
             assert torch.equal(got[k], want[k]), k
 
 
-def test_a_dead_graph_in_a_reference_cycle_does_not_abort_the_next_capture():
+def test_a_dead_graph_in_a_reference_cycle_does_not_abort_the_next_capture(monkeypatch):
     """Python's cycle collector may run at any allocation.  If it destroys an old captured step while a new one is
     being captured the runtime refuses and the process aborts (seen in bench.py: a whole run lost in its last
     section); every capture of hipvae.graph therefore collects first and keeps the collector quiet until it has
@@ -656,8 +656,10 @@ def test_a_dead_graph_in_a_reference_cycle_does_not_abort_the_next_capture():
     import weakref
     import models
     from hipvae import losses
+    import hipvae.graph as graph_module
     from hipvae.graph import GraphedTrainStep
     from hipvae.optim import FusedAdam
+    monkeypatch.setattr(graph_module, '_KEPT', None)      # the session keeps graphs alive; here they must be able to die
     cfg = dict(content_dim=8, motion_dim=8, content_channels=[4, 8, 16, 32], motion_channels=[4, 8],
                decoder_channels=[32, 16, 8, 4], content_feature_dim=32, motion_feature_dim=32, lstm_hidden=16,
                lstm_layers=1, bidirectional=True, sequence_length=6)
@@ -693,3 +695,23 @@ def test_a_dead_graph_in_a_reference_cycle_does_not_abort_the_next_capture():
     torch.cuda.synchronize()
     assert seen and all(enabled is False and not any(alive) for enabled, alive in seen), seen
     assert gc.isenabled() == was
+
+
+def test_graphs_kept_alive_on_request():
+    """hipvae.graph.keep_graphs_alive(): every captured graph is held until the process ends (or the switch goes
+    off), so that no graph is destroyed while others are still to be built (see its docstring)."""
+    import hipvae.graph as graph_module
+    import models
+    from hipvae.graph import GraphedForward
+    before = graph_module._KEPT
+    try:
+        graph_module.keep_graphs_alive()
+        m = models.BaselineVAE(latent_dim=8, encoder_channels=[4, 8, 16, 32], decoder_channels=[32, 16, 8, 4],
+                               feature_dim=32, sequence_length=4).cuda().eval()
+        v = synthetic_clips(2, 4, 5).cuda()
+        g = GraphedForward(m, v)
+        assert graph_module._KEPT == [g.graph]
+        graph_module.keep_graphs_alive(False)
+        assert graph_module._KEPT is None
+    finally:
+        graph_module._KEPT = before
