@@ -596,30 +596,64 @@ struct LossFinishArgs {
 __global__ void __launch_bounds__(1024) vae_loss_finish_kernel(LossFinishArgs a) {
   __shared__ double red[6][16];
   const int wave = threadIdx.x >> 6;
+  // One workgroup on an otherwise idle chip: what this kernel costs is the number of memory round trips a thread
+  // makes one after the other, so every loop below requests a batch of independent loads before it uses any.
   double s_rec = 0.0, s_tmp = 0.0;
-  for (int i = threadIdx.x; i < a.nparts; i += 1024) {
-    s_rec += a.partials[2 * i];
-    s_tmp += a.partials[2 * i + 1];
+  {
+    for (int i0 = threadIdx.x; i0 < a.nparts; i0 += 4 * 1024) {
+      double r[4], t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 1024 * u;
+        r[u] = i < a.nparts ? a.partials[2 * i] : 0.0;
+        t[u] = i < a.nparts ? a.partials[2 * i + 1] : 0.0;
+      }
+      s_rec += (r[0] + r[1]) + (r[2] + r[3]);
+      s_tmp += (t[0] + t[1]) + (t[2] + t[3]);
+    }
   }
   double kf[2] = {0.0, 0.0}, kr[2] = {0.0, 0.0};
   const int64_t rows = (int64_t)a.B;
   for (int p = 0; p < a.nkl; ++p) {
     const int64_t n = rows * a.D[p];
-    double s_floor[4] = {0.0, 0.0, 0.0, 0.0}, s_raw[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int64_t i0 = threadIdx.x; i0 < n; i0 += 4096) {
+    double s_floor = 0.0, s_raw = 0.0;
+    const bool quads = n % 4 == 0 && ((((uintptr_t)a.mu[p]) | ((uintptr_t)a.lv[p])) & 15) == 0;
+    if (quads) {
+      const float4* mu4 = reinterpret_cast<const float4*>(a.mu[p]);
+      const float4* lv4 = reinterpret_cast<const float4*>(a.lv[p]);
+      const int64_t n4 = n / 4;
+      constexpr int U = 8;                     // 8 x 1024 threads x 4 values: a 256 x 128 latent in one pass
+      for (int64_t i0 = threadIdx.x; i0 < n4; i0 += U * 1024) {
+        float4 m[U], l[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t i = i0 + 1024 * u;
-        if (i < n) {
-          const float m = a.mu[p][i], lv = a.lv[p][i];
-          const float kl = -0.5f * (1.f + lv - m * m - expf(lv));
-          s_raw[u] += (double)kl;
-          s_floor[u] += (double)((a.free_bits > 0.f) ? fmaxf(kl, a.free_bits) : kl);
+        for (int u = 0; u < U; ++u) {
+          const int64_t i = i0 + 1024 * u;
+          m[u] = i < n4 ? mu4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+          l[u] = i < n4 ? lv4[i] : make_float4(0.f, 0.f, 0.f, 0.f);       // kl(0, 0) = 0 ...
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (i0 + 1024 * u < n4) {                                         // ... but the floor of a free-bits term is not
+            const float mm[4] = {m[u].x, m[u].y, m[u].z, m[u].w}, ll[4] = {l[u].x, l[u].y, l[u].z, l[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float kl = -0.5f * (1.f + ll[e] - mm[e] * mm[e] - expf(ll[e]));
+              s_raw += (double)kl;
+              s_floor += (double)((a.free_bits > 0.f) ? fmaxf(kl, a.free_bits) : kl);
+            }
+          }
         }
       }
+    } else {
+      for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float m = a.mu[p][i], lv = a.lv[p][i];
+        const float kl = -0.5f * (1.f + lv - m * m - expf(lv));
+        s_raw += (double)kl;
+        s_floor += (double)((a.free_bits > 0.f) ? fmaxf(kl, a.free_bits) : kl);
+      }
     }
-    kf[p] = (s_floor[0] + s_floor[1]) + (s_floor[2] + s_floor[3]);
-    kr[p] = (s_raw[0] + s_raw[1]) + (s_raw[2] + s_raw[3]);
+    kf[p] = s_floor;
+    kr[p] = s_raw;
   }
   const double v[6] = {s_rec, s_tmp, kf[0], kr[0], kf[1], kr[1]};
 #pragma unroll
