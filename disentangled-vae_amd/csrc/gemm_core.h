@@ -548,7 +548,10 @@ __device__ __forceinline__ f32x4 zero_unless(f32x4 v, bool keep) {
 
 // KC: tile rows are matrix rows (R of them starting at row0), k along the contiguous dimension.
 // Everything that does not move with the K tile (row pointer, row validity) is set up once.
-template <int V4>
+// WHOLE: the caller vouches that every row of the tile exists and that K is a multiple of 32; issue() is then
+// nothing but the loads and finish() nothing at all (with bf16 operands the multiplies of a K tile are so short
+// that the address selects and zero masks of the general form are a fifth of the step).
+template <int V4, bool WHOLE = false>
 struct KCLoader {
   const float* base;
   const float* rowp[V4];
@@ -572,6 +575,11 @@ struct KCLoader {
   __device__ __forceinline__ void issue(int kt, f32x4 (&r)[V4]) { issue_at(kt * 32, r); }
   // the K tile that starts at k0 (callers that walk K in an order of their own)
   __device__ __forceinline__ void issue_at(int k0, f32x4 (&r)[V4]) {
+    if (WHOLE) {
+#pragma unroll
+      for (int v = 0; v < V4; ++v) r[v] = ldg4(rowp[v] + k0);
+      return;
+    }
     mask = (k0 + kofs < K) ? rowok : 0u;
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
@@ -580,6 +588,7 @@ struct KCLoader {
     }
   }
   __device__ __forceinline__ void finish(f32x4 (&r)[V4]) const {
+    if (WHOLE) return;
 #pragma unroll
     for (int v = 0; v < V4; ++v) r[v] = zero_unless(r[v], (mask >> v) & 1u);
   }
@@ -591,7 +600,7 @@ struct KCLoader {
 
 // RC: tile "rows" index the contiguous dimension of memory (R of them starting at col0); k walks
 // the strided dimension.  256 % (R/4) == 0, so a thread keeps its column for every chunk it loads.
-template <int V4, int R, bool KADJ = false>
+template <int V4, int R, bool KADJ = false, bool WHOLE = false>
 struct RCLoader {
   static_assert(256 % (R / 4) == 0, "column position must not depend on the chunk number");
   const float* base;
@@ -608,6 +617,11 @@ struct RCLoader {
     colp = base + (colok ? (int64_t)((KADJ ? V4 : 1) * kr0) * ld + c : 0);
   }
   __device__ __forceinline__ void issue(int kt, f32x4 (&r)[V4]) {
+    if (WHOLE) {
+#pragma unroll
+      for (int v = 0; v < V4; ++v) r[v] = ldg4(colp + (int64_t)(kt * 32 + (KADJ ? v : v * (1024 / R))) * ld);
+      return;
+    }
     mask = 0;
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
@@ -620,6 +634,7 @@ struct RCLoader {
     }
   }
   __device__ __forceinline__ void finish(f32x4 (&r)[V4]) const {
+    if (WHOLE) return;
 #pragma unroll
     for (int v = 0; v < V4; ++v) r[v] = zero_unless(r[v], (mask >> v) & 1u);
   }
