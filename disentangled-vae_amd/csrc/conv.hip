@@ -17,6 +17,9 @@
 
 #define ST(s) ((hipStream_t)(s))
 #define CONV_MAX_PARTS 1024
+#ifndef DVAE_CONV_WHOLE_B
+#define DVAE_CONV_WHOLE_B 1
+#endif
 // timing-only build (-DDVAE_CONV_EPILOGUE_PROBE=1): the tiled forward kernels without their output stores and
 // without the loads of the BatchNorm-backward operand, i.e. what the epilogue's memory traffic costs
 #ifndef DVAE_CONV_EPILOGUE_PROBE
@@ -374,20 +377,22 @@ struct ConvALoader {
 };
 
 // B operand (packed filter [Cout][K]) read in the K order of the A operand
-template <int V4, int MODE>
+template <int V4, int MODE, bool WHOLE = false>
 struct ConvBLoader {
-  KCLoader<V4> l;
+  KCLoader<V4, WHOLE> l;
   const ConvArgs& g;
   __device__ __forceinline__ ConvBLoader(const ConvArgs& g_, const float* base, int64_t n0)
       : l(base, (int64_t)g_.K, (int64_t)g_.Cout, (int64_t)g_.K, n0), g(g_) {}
   __device__ __forceinline__ void issue(int kt, f32x4 (&r)[V4]) { l.issue_at(conv_walk_k0<MODE>(g, kt), r); }
   __device__ __forceinline__ void finish(f32x4 (&r)[V4]) const { l.finish(r); }
-  typedef typename KCLoader<V4>::Tag Tag;
+  typedef typename KCLoader<V4, WHOLE>::Tag Tag;
   __device__ __forceinline__ Tag tag() const { return l.tag(); }
   __device__ __forceinline__ void set_tag(const Tag& t) { l.set_tag(t); }
 };
 
-template <class T, int MODE, bool C1, int BF, bool BNS>      // BF: PREC_F32, PREC_BF16 or PREC_SPLIT
+// BF: PREC_F32, PREC_BF16 or PREC_SPLIT.  BW: every column tile lies inside the filter and K is whole K tiles, so the
+// filter loader needs no address selects and no zero masks
+template <class T, int MODE, bool C1, int BF, bool BNS, bool BW = false>
 __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * Core<T, BF>::STAGE];
   // transposed conv: the four sub-pixel phases of one M tile share its input tile.  Workgroups go to
@@ -417,7 +422,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
   const int l31 = lane & 31;
 
   ConvALoader<T::A_V4, MODE, C1> la(g, ph, pw);
-  ConvBLoader<T::B_V4, MODE> lb(g, g.wp + (int64_t)phase * g.Cout * g.K, n0);
+  ConvBLoader<T::B_V4, MODE, BW> lb(g, g.wp + (int64_t)phase * g.Cout * g.K, n0);
 
   float s1[T::TN], s2[T::TN];
 #pragma unroll
@@ -1488,17 +1493,23 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
       if (C1FLAG) DVAE_WORK(4.0 * ((double)rows_ * 4 + (double)rows_ * g.Cout), DVAE_UNIT_BYTE);     \
       else DVAE_WORK(2.0 * (double)rows_ * phases * g.Cout * g.K, DVAE_UNIT_FLOP);                   \
     }                                                                                                \
+    const bool bw_ = DVAE_CONV_WHOLE_B && !(C1FLAG) && g.Cout % TILE::BN == 0 && g.K % 32 == 0;        \
     if (bns && !(C1FLAG)) {                                                                          \
       if (bf)                                                                                        \
-        DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, (C1FLAG) ? PREC_F32 : PREC_BF16, !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
+        CONV_FWD_LAUNCH(TILE, C1FLAG, (C1FLAG) ? PREC_F32 : PREC_BF16, !(C1FLAG))                    \
       else                                                                                           \
-        DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, PREC_F32, !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
+        CONV_FWD_LAUNCH(TILE, C1FLAG, PREC_F32, !(C1FLAG))                                           \
     } else if (bf && !(C1FLAG))                                                                      \
-      DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, (C1FLAG) ? PREC_F32 : PREC_BF16, false>), grid, dim3(256), 0, stream, g); \
+      CONV_FWD_LAUNCH(TILE, C1FLAG, (C1FLAG) ? PREC_F32 : PREC_BF16, false)                          \
     else if (sp && !(C1FLAG))                                                                        \
-      DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, (C1FLAG) ? PREC_F32 : PREC_SPLIT, false>), grid, dim3(256), 0, stream, g); \
+      CONV_FWD_LAUNCH(TILE, C1FLAG, (C1FLAG) ? PREC_F32 : PREC_SPLIT, false)                         \
     else                                                                                             \
-      DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, PREC_F32, false>), grid, dim3(256), 0, stream, g); \
+      CONV_FWD_LAUNCH(TILE, C1FLAG, PREC_F32, false)                                                 \
+  }
+#define CONV_FWD_LAUNCH(TILE, C1FLAG, PREC_, BNS_)                                                             \
+  {                                                                                                            \
+    if (bw_) DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, PREC_, BNS_, !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
+    else DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, PREC_, BNS_, false>), grid, dim3(256), 0, stream, g);  \
   }
   int mt_begin = 0, mt_end = -1;       // M-tile range of the next LAUNCH (-1: the whole layer)
   int ksplit = 1;                      // gridDim.z of the next LAUNCH
@@ -1718,6 +1729,7 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
     }
   }
 #undef LAUNCH
+#undef CONV_FWD_LAUNCH
   DVAE_LAUNCH_CHECK(name);
   return 0;
 }
