@@ -252,7 +252,8 @@ __device__ __forceinline__ int conv_walk_k0(const ConvArgs& g, int kt) {
 // bit test and one address add per 16-byte load.  issue() only starts loads (masked-out chunks read
 // x[0..3], which is always there, and are zeroed in finish()); the BatchNorm scale/shift of the K
 // tile's channels ride along as two more loads in flight.  K tiles may be visited in any order.
-template <int V4, int MODE, bool C1>
+// NOXF: the caller vouches that the input takes no BatchNorm affine and no activation on its way in
+template <int V4, int MODE, bool C1, bool NOXF = false>
 struct ConvALoader {
   const ConvArgs& g;
   int ph, pw;
@@ -334,7 +335,7 @@ struct ConvALoader {
     }
     const int tapoff = MODE == 0 ? (tp >> 2) * g.W + (tp & 3) : -((tp >> 1) * g.W + (tp & 1));
     const int toff = tapoff * g.Cin + ci;
-    if (g.in_scale) {
+    if (!NOXF && g.in_scale) {
       const int cs = kok ? ci : 0;
       sc = *reinterpret_cast<const float4*>(g.in_scale + cs);
       sh = *reinterpret_cast<const float4*>(g.in_shift + cs);
@@ -364,11 +365,11 @@ struct ConvALoader {
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
       f32x4 val = r[v];
-      if (g.in_scale) {
+      if (!NOXF && g.in_scale) {
         val.x = fmaf(val.x, sc.x, sh.x); val.y = fmaf(val.y, sc.y, sh.y);
         val.z = fmaf(val.z, sc.z, sh.z); val.w = fmaf(val.w, sc.w, sh.w);
       }
-      if (g.in_act == DVAE_ACT_LRELU) {
+      if (!NOXF && g.in_act == DVAE_ACT_LRELU) {
         val.x = lrelu(val.x); val.y = lrelu(val.y); val.z = lrelu(val.z); val.w = lrelu(val.w);
       }
       r[v] = zero_unless(val, (mask >> v) & 1u);
@@ -390,9 +391,9 @@ struct ConvBLoader {
   __device__ __forceinline__ void set_tag(const Tag& t) { l.set_tag(t); }
 };
 
-// BF: PREC_F32, PREC_BF16 or PREC_SPLIT.  BW: every column tile lies inside the filter and K is whole K tiles, so the
-// filter loader needs no address selects and no zero masks
-template <class T, int MODE, bool C1, int BF, bool BNS, bool BW = false>
+// BF: PREC_F32, PREC_BF16 or PREC_SPLIT.  LEAN >= 1: every column tile lies inside the filter and K is whole K tiles,
+// so the filter loader needs no address selects and no zero masks; LEAN == 2: the input also takes no transform
+template <class T, int MODE, bool C1, int BF, bool BNS, int LEAN = 0>
 __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * Core<T, BF>::STAGE];
   // transposed conv: the four sub-pixel phases of one M tile share its input tile.  Workgroups go to
@@ -421,8 +422,8 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs g) {
   const int wm = wave / T::WGN, wn = wave % T::WGN;
   const int l31 = lane & 31;
 
-  ConvALoader<T::A_V4, MODE, C1> la(g, ph, pw);
-  ConvBLoader<T::B_V4, MODE, BW> lb(g, g.wp + (int64_t)phase * g.Cout * g.K, n0);
+  ConvALoader<T::A_V4, MODE, C1, LEAN == 2> la(g, ph, pw);
+  ConvBLoader<T::B_V4, MODE, (LEAN >= 1)> lb(g, g.wp + (int64_t)phase * g.Cout * g.K, n0);
 
   float s1[T::TN], s2[T::TN];
 #pragma unroll
@@ -1508,8 +1509,10 @@ static int launch_conv_fwd(const char* name, ConvArgs g, int phases, hipStream_t
   }
 #define CONV_FWD_LAUNCH(TILE, C1FLAG, PREC_, BNS_)                                                             \
   {                                                                                                            \
-    if (bw_) DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, PREC_, BNS_, !(C1FLAG)>), grid, dim3(256), 0, stream, g); \
-    else DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, PREC_, BNS_, false>), grid, dim3(256), 0, stream, g);  \
+    if (bw_ && g.in_scale == nullptr && g.in_act == DVAE_ACT_NONE)                                              \
+      DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, PREC_, BNS_, (C1FLAG) ? 0 : 2>), grid, dim3(256), 0, stream, g); \
+    else if (bw_) DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, PREC_, BNS_, (C1FLAG) ? 0 : 1>), grid, dim3(256), 0, stream, g); \
+    else DVAE_LAUNCH((conv_fwd_kernel<TILE, MODE, C1FLAG, PREC_, BNS_, 0>), grid, dim3(256), 0, stream, g);      \
   }
   int mt_begin = 0, mt_end = -1;       // M-tile range of the next LAUNCH (-1: the whole layer)
   int ksplit = 1;                      // gridDim.z of the next LAUNCH
