@@ -6,6 +6,9 @@
 
 enum { G_NT = 0, G_NN = 1, G_TN = 2 };
 // bf16 operands: three workgroups per CU (the output tile leaves through LDS in two runs of rows)
+#ifndef DVAE_NT_AHEAD2
+#define DVAE_NT_AHEAD2 1
+#endif
 #ifndef DVAE_GEMM_WHOLE_TILES
 #define DVAE_GEMM_WHOLE_TILES 1
 #endif
@@ -81,14 +84,16 @@ __global__ void __launch_bounds__(256, ((DVAE_GEMM_ONE_STAGE && KIND == G_NT && 
   const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
 #endif
   // whole tile, whole K tiles: loaders without address selects and zero masks (see KCLoader).  With bf16 operands
-  // 8-13 % of a large product; with fp32 operands 5-10 % of the NN and TN products, whose loads run two K tiles ahead
-  // (nothing, or a loss on short K, for the NT products, which keep the general loaders).
+  // 8-13 % of a large product; with fp32 operands 5-10 % of the NN and TN products, whose loads run two K tiles
+  // ahead, and 7-13 % of the NT products when they take that loop as well (with the general loaders it costs them
+  // registers and gains nothing; with these loaders alone, nothing).
   const bool whole = m0 + T::BM <= g.M && n0 + T::BN <= g.N && g.K % 32 == 0;
 #define GEMM_RUN(W)                                                                                    \
   if (KIND == G_NT) {                                                                                  \
     KCLoader<T::A_V4, W> la(g.A, g.lda, g.M, g.K, m0);                                                 \
     KCLoader<T::B_V4, W> lb(g.B, g.ldb, g.N, g.K, n0);                                                 \
-    gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);                                         \
+    if (DVAE_NT_AHEAD2 && BF == PREC_F32 && W) gemm_mainloop_ahead2<T, BF>(la, lb, kt_begin, kt_end, smem, acc); \
+    else gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);                                    \
   } else if (KIND == G_NN) {                                                                           \
     KCLoader<T::A_V4, W> la(g.A, g.lda, g.M, g.K, m0);                                                 \
     RCLoader<T::B_V4, T::BN, Core<T, BF>::KADJ, W> lb(g.B, g.ldb, g.N, g.K, n0);                       \
@@ -100,7 +105,7 @@ __global__ void __launch_bounds__(256, ((DVAE_GEMM_ONE_STAGE && KIND == G_NT && 
     if (BF == PREC_F32) gemm_mainloop_ahead2<T, BF>(la, lb, kt_begin, kt_end, smem, acc);              \
     else gemm_mainloop<T, BF>(la, lb, kt_begin, kt_end, smem, acc);                                    \
   }
-  if (DVAE_GEMM_WHOLE_TILES && (BF == PREC_BF16 || KIND != G_NT) && whole) {
+  if (DVAE_GEMM_WHOLE_TILES && (BF == PREC_BF16 || KIND != G_NT || DVAE_NT_AHEAD2) && whole) {
     GEMM_RUN(true)
   } else {
     GEMM_RUN(false)
