@@ -17,6 +17,8 @@
 
 #define ST(s) ((hipStream_t)(s))
 #define CONV_MAX_PARTS 1024
+// the tiled forward kernels' filter loader without selects and masks when every column tile lies inside the filter
+// (-DDVAE_CONV_WHOLE_B=0: always the general loader)
 #ifndef DVAE_CONV_WHOLE_B
 #define DVAE_CONV_WHOLE_B 1
 #endif

@@ -5,13 +5,16 @@
 #define ST(s) ((hipStream_t)(s))
 
 enum { G_NT = 0, G_NN = 1, G_TN = 2 };
-// bf16 operands: three workgroups per CU (the output tile leaves through LDS in two runs of rows)
+// Build-time switches, each the shipped choice of an A/B that -D...=0 takes back:
+// fp32 NT products on whole tiles keep two K tiles of loads in flight, like the NN and TN products
 #ifndef DVAE_NT_AHEAD2
 #define DVAE_NT_AHEAD2 1
 #endif
+// whole tiles take loaders without address selects and zero masks (KCLoader / RCLoader <..., WHOLE>)
 #ifndef DVAE_GEMM_WHOLE_TILES
 #define DVAE_GEMM_WHOLE_TILES 1
 #endif
+// bf16 operands: three workgroups per CU (the output tile leaves through LDS in two runs of rows)
 #ifndef DVAE_BF16_WG3
 #define DVAE_BF16_WG3 1
 #endif
