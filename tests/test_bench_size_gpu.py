@@ -149,7 +149,8 @@ def test_gemm_at_bench_size(ops, M, N, K):
 
 
 # bf16-MFMA variant (with the decoder's largest tensors stored as bf16), full width, batch 256: bar on the per-tensor
-# gradient error = 1.5 x the worst value measured on MI355X (1.087e-1 with the final kernels of the round, 1.063e-1 before their K order changed; profiles/r3_parity_b256.txt)
+# gradient error = 1.5 x the worst value measured on MI355X (1.087e-1; 1.063e-1 before the tiled kernels' K order
+# changed; profiles/r3_parity_b256.txt)
 BF16_GRAD_BAR = 1.63e-1
 
 
